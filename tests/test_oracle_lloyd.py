@@ -1,0 +1,43 @@
+"""The Lloyd oracle (oracle/lloyd_ref.c) against vectors produced by the installed scikit-learn
+(tests/golden/make_lloyd_goldens.py) -- this is what pins it."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lloyd_goldens.npz"))
+CASES = sorted({k.split("/")[0] for k in Z.files if "/" in k})
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fit_matches_sklearn(name):
+    X, C0 = Z[name + "/X"], Z[name + "/C0"]
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, C0, int(Z[name + "/max_iter"]), float(Z[name + "/tol"]))
+    assert n_iter == int(Z[name + "/n_iter"])
+    assert np.array_equal(lab, Z[name + "/labels"])            # bit-exact labels
+    assert np.abs(cen - Z[name + "/centers"]).max() <= 1e-11   # sklearn's own thread-order noise is 6e-14
+    assert abs(inertia - float(Z[name + "/inertia"])) <= 1e-12 * float(Z[name + "/inertia"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_predict_matches_sklearn(name):
+    X = Z[name + "/X"]
+    assert np.array_equal(O.kmeans_predict(X, Z[name + "/centers"]), Z[name + "/predict"])
+
+
+def test_too_few_samples_raises():
+    with pytest.raises(ValueError):
+        O.kmeans_fit(np.zeros((2, 4), np.uint8), np.zeros((3, 4)))
+
+
+def test_partials_sum_to_full_step():
+    """two shards' partials add up to the one-shard partials (exact: integer-valued data)"""
+    X = Z["cell_u8_k3/X"]
+    C0 = Z["cell_u8_k3/C0"]
+    mean = np.zeros(4)
+    full = O.lloyd_partials(X, mean, C0, np.full(len(X), -1, np.int32))
+    a = O.lloyd_partials(X[:1000], mean, C0, np.full(1000, -1, np.int32))
+    b = O.lloyd_partials(X[1000:], mean, C0, np.full(len(X) - 1000, -1, np.int32))
+    assert np.array_equal(a + b, full)
