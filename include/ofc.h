@@ -1,0 +1,185 @@
+/*
+ * ofc.h -- C ABI of libofc.so: the MI355X (gfx950) implementation of the dense-Farneback-flow ->
+ * k-means hot path of menmitsu/opticalFlowClustering.
+ *
+ * The reference has no FFI of its own for this path: it reaches the arithmetic through the Python
+ * call signatures of cv2 and scikit-learn.  Each entry point below names the reference call it
+ * stands in for (file:line relative to k-means-color-clustering/ in the reference).  The Python
+ * host side (opticalflowclustering_amd/) binds these with ctypes and re-exposes the reference's
+ * own class / function / CLI names on top.
+ *
+ * Conventions
+ *   - plain C types only; all buffers C-contiguous; images are row-major, stride == width.
+ *   - "host" pointers are ordinary process memory; "_dev" entry points take device pointers
+ *     obtained from ofc_malloc (or any hipMalloc'ed memory of the same device).
+ *   - every call returns 0 on success or a negative OFC_E* code; ofc_last_error() gives the
+ *     message for the calling host thread.  No C++ exception crosses the ABI.
+ *   - handles are not thread-safe; use one per (host thread, GPU).
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails with
+ *     OFC_ENODEV.
+ */
+#ifndef OFC_H
+#define OFC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFC_VERSION 100 /* 0.1.0 */
+
+enum {
+    OFC_OK = 0,
+    OFC_EINVAL = -1,   /* bad argument (maps to Python ValueError) */
+    OFC_ENODEV = -2,   /* no usable GPU / HIP runtime error at init */
+    OFC_EHIP = -3,     /* HIP runtime error during the call */
+    OFC_ENOMEM = -4,   /* device allocation failed */
+    OFC_ENOTREADY = -5,/* streaming flow: first frame pushed, no pair yet */
+    OFC_EUNSUPPORTED = -6, /* parameter combination outside what the kernels implement */
+    OFC_ECOMM = -7     /* RCCL error */
+};
+
+enum { OFC_U8 = 0, OFC_F32 = 1, OFC_F64 = 2 };
+
+int ofc_version(void);
+const char *ofc_last_error(void);
+int ofc_device_count(int *n);
+
+/* ---- device memory plumbing (so a host without torch can keep inputs resident in HBM) ---- */
+int ofc_malloc(int device, size_t bytes, void **dptr);
+int ofc_free(int device, void *dptr);
+int ofc_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int ofc_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int ofc_memset(int device, void *dst_dev, int value, size_t bytes);
+int ofc_device_sync(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense Farneback flow.
+ * Replaces cv2.calcOpticalFlowFarneback(prev, next, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+ * (computeOpticalFlowModule.py:20-22, computeOpticalFlow.py:99-101).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ofc_fb_params {
+    double pyr_scale;  /* 0.5 */
+    int levels;        /* 3   */
+    int winsize;       /* 15  */
+    int iterations;    /* 3   */
+    int poly_n;        /* 5   */
+    double poly_sigma; /* 1.2 */
+    int flags;         /* 0   */
+} ofc_fb_params;
+
+void ofc_fb_default_params(ofc_fb_params *p);
+
+typedef struct ofc_flow ofc_flow_t;
+
+/* one engine per (device, resolution).  max_batch = the largest number of frame PAIRS processed
+ * per call of ofc_flow_calc_frames_dev; all scratch (pyramid images, polynomial expansions R,
+ * matrices M, per-level flows) is allocated here once. */
+int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_batch,
+                    ofc_flow_t **out);
+void ofc_flow_destroy(ofc_flow_t *f);
+
+/* one isolated pair, host buffers: prev/next HxW u8 -> flow HxWx2 f32 (u = x-disp, v = y-disp) */
+int ofc_flow_calc(ofc_flow_t *f, const uint8_t *prev_gray, const uint8_t *next_gray,
+                  float *flow_out);
+
+/* batched, device-resident: n_frames consecutive HxW u8 frames -> (n_frames-1) flows,
+ * flow_dev[(t*H + y)*W + x][2] between frame t and t+1.  n_frames-1 <= max_batch.
+ * Asynchronous on the engine's stream; ofc_flow_sync() (or ofc_device_sync) completes it. */
+int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames,
+                             float *flow_dev);
+int ofc_flow_sync(ofc_flow_t *f);
+
+/* streaming form of ComputeOpticalFLow (computeOpticalFlowModule.py:6-36): keeps the previous
+ * frame; the first push returns OFC_ENOTREADY and writes nothing. */
+int ofc_flow_push_gray(ofc_flow_t *f, const uint8_t *gray, float *flow_out);
+
+/* ---- single stages, host buffers (parity-test / bench hooks; interleaved layouts as OpenCV's
+ *      internals so they compare 1:1 with the oracle) ---- */
+/* u8 frame -> f32 pyramid image of level k (GaussianBlur at full res + INTER_LINEAR resize) */
+int ofc_level_image(int device, const uint8_t *gray, int W, int H, const ofc_fb_params *p, int k,
+                    float *out, int *w_out, int *h_out);
+/* FarnebackPolyExp: f32 HxW -> f32 HxWx5 {y-lin, x-lin, y^2, x^2, xy} */
+int ofc_polyexp(int device, const float *img, int W, int H, int n, double sigma, float *R5);
+/* FarnebackUpdateMatrices: R0,R1 HxWx5, flow HxWx2 -> M HxWx5 */
+int ofc_update_matrices(int device, const float *R0, const float *R1, const float *flow, int W,
+                        int H, float *M);
+/* box mean (winsize) of M + 2x2 solve: M HxWx5 -> flow HxWx2 */
+int ofc_box_solve(int device, const float *M, int W, int H, int winsize, float *flow);
+/* resize(flow, (w,h), INTER_LINEAR) * mul */
+int ofc_flow_resize(int device, const float *flow, int sw, int sh, int dw, int dh, float mul,
+                    float *out);
+
+/* bench hook: time `iters` launches of the polyexp kernel over n_images distinct resident images
+ * with HIP events on the kernel's own stream; *ms_per_launch = average launch duration. */
+int ofc_bench_polyexp(int device, int W, int H, int n_images, int iters, int rows_per_block,
+                      float *ms_per_launch);
+
+/* ------------------------------------------------------------------------------------------
+ * Flow visualisation and grid.
+ * ------------------------------------------------------------------------------------------ */
+/* cvtColor(BGR2GRAY) u8 (computeOpticalFlowModule.py:16,19) */
+int ofc_bgr2gray(int device, const uint8_t *bgr, int W, int H, uint8_t *gray);
+/* cartToPolar + hue/normalize(MINMAX)/HSV2BGR (computeOpticalFlowModule.py:25-33) and
+ * np.mean(magnitude) (computeOpticalFlow.py:114-117): flow HxWx2 f32 -> bgr HxWx3 u8 */
+int ofc_flow_to_bgr(int device, const float *flow, int W, int H, uint8_t *bgr, float *mean_mag);
+int ofc_flow_to_bgr_dev(int device, const float *flow_dev, int W, int H, int n_frames,
+                        uint8_t *bgr_dev, float *mean_mag_dev);
+/* overlayGridAndComputeAvgColor (KmeanGrids.py:52-113): per-cell mean BGR -> u8 -> BGR2HSV.
+ * mean_bgr, hsv: rows*cols x 3 u8 */
+int ofc_grid_cell_means(int device, const uint8_t *bgr, int W, int H, int rows, int cols,
+                        uint8_t *mean_bgr, uint8_t *hsv);
+
+/* ------------------------------------------------------------------------------------------
+ * Lloyd k-means.  Replaces sklearn.cluster.KMeans(n_clusters=k, init=<k x d>, n_init=1,
+ * max_iter, tol).fit(X) / .predict(X) (color_kmeans.py:66-78, KmeanGrids.py:300-304).
+ * All arithmetic in f64 whatever the storage dtype (sklearn casts u8 to f64).
+ * ------------------------------------------------------------------------------------------ */
+/* host buffers. X: N x d of `dtype`; init: k x d f64 (required: explicit init = determinism);
+ * centers k x d f64, labels N i32, inertia, n_iter as sklearn's attributes of the same name. */
+int ofc_kmeans_fit(int device, const void *X, int dtype, int64_t N, int d, int k,
+                   const double *init, int max_iter, double tol_rel, double *centers,
+                   int32_t *labels, double *inertia, int *n_iter);
+/* KMeans.predict: one E-step of the un-centred X against `centers` */
+int ofc_kmeans_predict(int device, const void *X, int dtype, int64_t N, int d, int k,
+                       const double *centers, int32_t *labels);
+/* device-resident X (e.g. the (u,v) field ofc_flow_calc_frames_dev just wrote); labels_dev is
+ * N x u8 (k <= 255) or NULL.  If a communicator was set up with ofc_dist_init the partial sums are
+ * all-reduced over the ranks every iteration (X is then this rank's shard). */
+int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k,
+                       const double *init, int max_iter, double tol_rel, double *centers,
+                       uint8_t *labels_dev, double *inertia, int *n_iter);
+/* many small independent problems in one launch (the per-grid-cell shape of KmeanGrids.py:376-392):
+ * problem p owns rows [offsets[p], offsets[p+1]) of X (u8, d = 4); init/centers: P x k x d f64;
+ * counts: P x k i32 = np.bincount(predict(X)); labels may be NULL. */
+int ofc_kmeans_fit_batched(int device, const uint8_t *X, const int64_t *offsets, int n_problems,
+                           int d, int k, const double *init, int max_iter, double tol_rel,
+                           double *centers, int32_t *counts, int32_t *labels, int *n_iter);
+/* the whole per-frame tail of KmeanGrids.py:376-392 on the device: grid cells of a BGR frame
+ * (white row 0 / column 0 as cv2.rectangle leaves them) -> preprocess_image -> KMeans(k) ->
+ * dominant cluster -> rint -> BGR2HSV.  init: cells x k x 4 f64.  centers: cells x 4 f64 (dominant
+ * centre, rounded); hsv: cells x 3 u8.  channel_order: 0 = BGR as in memory (KmeanGrids.py:385),
+ * 1 = swap to RGB first (the disk path, color_kmeansChange.py:33). */
+int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int cols, int k,
+                    const double *init, int max_iter, double tol_rel, int channel_order,
+                    double *centers, uint8_t *hsv);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU; frames (hence (u,v) points) are sharded by rank; the only
+ * exchange is one all-reduce (sum, f64) of [k*d sums | k counts | n_changed] per Lloyd iteration.
+ * ------------------------------------------------------------------------------------------ */
+#define OFC_UNIQUE_ID_BYTES 128
+int ofc_dist_unique_id(uint8_t id[OFC_UNIQUE_ID_BYTES]);          /* rank 0, then broadcast */
+int ofc_dist_init(int device, int rank, int world, const uint8_t id[OFC_UNIQUE_ID_BYTES]);
+int ofc_dist_allreduce_f64(int device, double *buf_dev, int count); /* test hook */
+int ofc_dist_finalize(void);
+
+/* ---- synthetic input generator used by bench.py (not part of the reference path) ---- */
+int ofc_synth_frames_dev(int device, uint8_t *frames_dev, int W, int H, int n_frames,
+                         int t0, int seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFC_H */

@@ -1,0 +1,570 @@
+// flow_kernels.hip -- hand-written gfx950 kernels of the Farneback pyramid.
+//
+// All kernels are batched over images / frame pairs through blockIdx.z so that even the coarse
+// pyramid levels (240x135 at 1080p) fill the 256 CUs.  Layouts in HBM:
+//   frames  [n][H0][W0] u8            pyramid image I [n][h][w] f32
+//   R       [n][5][h][w] f32 planar   (OpenCV's interleaved 5-float pixel is an internal detail;
+//                                      planar gives every lane dword/float4-coalesced stores)
+//   M       [p][5][h][w] f32 planar   flow [p][h][w][2] f32 (the ABI layout of cv2's output)
+//
+// Arithmetic follows the oracle (oracle/farneback_ref.c == SURVEY.md App. A) statement by statement.
+// Kernels that are purely memory bound keep FP contraction OFF so that they reproduce the oracle
+// bit for bit; polyexp and the box filter use FMAs / exact f64 sums (differences ~1e-7 relative).
+#include "ofc_common.h"
+
+namespace ofc {
+
+// ------------------------------------------------------------------------------------------------
+// bilinear tap helpers (imgproc resize INTER_LINEAR)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_tap_x(int dx, double scale, int sw, int &s0, float &a)
+{
+#pragma clang fp contract(off)
+    float fx = (float)((dx + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+    s0 = sx;
+    a = fx;
+}
+
+__device__ __forceinline__ void lin_tap_y(int dy, double scale, int sh, int &s0, int &s1, float &b)
+{
+#pragma clang fp contract(off)
+    float fy = (float)((dy + 0.5) * scale - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    s0 = min(max(sy, 0), sh - 1);
+    s1 = min(max(sy + 1, 0), sh - 1);
+    b = fy;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  blur + decimate:  u8 full-res frame -> f32 level image.
+// The separable Gaussian (REFLECT_101) is evaluated ONLY at the <=2x2 full-res positions each output
+// pixel's bilinear taps touch: 1/4 .. 1/16 of the work of blurring the whole frame per level.
+// LDS: u8 input tile (+halo) and the row-filtered samples.  HBM-bound on the u8 read (1 B/px of the
+// full-res frame per level) -- SURVEY.md 8d.
+// ------------------------------------------------------------------------------------------------
+struct LevelArgs {
+    int W0, H0, w, h;
+    int r;
+    int txo, tyo;
+    int in_w, in_h;      // LDS tile extents (upper bounds)
+    int in_pitch;        // u8 pitch, multiple of 4
+    double sx, sy;
+    float kern[32];
+};
+
+__global__ __launch_bounds__(256) void k_level_image(const uint8_t *__restrict__ src,
+                                                     float *__restrict__ dst, LevelArgs p)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * p.txo, oy0 = blockIdx.y * p.tyo;
+    const int nox = min(p.txo, p.w - ox0), noy = min(p.tyo, p.h - oy0);
+    const uint8_t *img = src + (size_t)blockIdx.z * p.W0 * p.H0;
+    float *out = dst + (size_t)blockIdx.z * p.w * p.h;
+
+    // LDS carve-up
+    int *xs0 = reinterpret_cast<int *>(smem);                   // [txo]
+    float *xa = reinterpret_cast<float *>(xs0 + p.txo);         // [txo]
+    int *ys0 = reinterpret_cast<int *>(xa + p.txo);             // [tyo]
+    int *ys1 = ys0 + p.tyo;                                     // [tyo]
+    float *yb = reinterpret_cast<float *>(ys1 + p.tyo);         // [tyo]
+    float *h1 = yb + p.tyo;                                     // [in_h][2*txo]
+    unsigned char *tile = reinterpret_cast<unsigned char *>(h1 + (size_t)p.in_h * 2 * p.txo);
+
+    if (tid < nox) {
+        int s0; float a;
+        lin_tap_x(ox0 + tid, p.sx, p.W0, s0, a);
+        xs0[tid] = s0; xa[tid] = a;
+    }
+    if (tid >= 64 && tid - 64 < noy) {
+        int s0, s1; float b;
+        lin_tap_y(oy0 + tid - 64, p.sy, p.H0, s0, s1, b);
+        ys0[tid - 64] = s0; ys1[tid - 64] = s1; yb[tid - 64] = b;
+    }
+    __syncthreads();
+    const int x_first = xs0[0], x_last = min(xs0[nox - 1] + 1, p.W0 - 1);
+    const int y_first = ys0[0], y_last = ys1[noy - 1];
+    const int ix0 = x_first - p.r, iy0 = y_first - p.r;
+    const int tw = x_last - x_first + 1 + 2 * p.r, th = y_last - y_first + 1 + 2 * p.r;
+
+    for (int i = tid; i < tw * th; i += 256) {
+        int ly = i / tw, lx = i - ly * tw;
+        int gx = reflect101(ix0 + lx, p.W0), gy = reflect101(iy0 + ly, p.H0);
+        tile[ly * p.in_pitch + lx] = img[(size_t)gy * p.W0 + gx];
+    }
+    __syncthreads();
+
+    // row pass (taps summed left to right) at the two x positions of every output column
+    const int ks = 2 * p.r + 1;
+    for (int i = tid; i < th * nox * 2; i += 256) {
+        int ly = i / (nox * 2), rem = i - ly * nox * 2;
+        int j = rem >> 1, t = rem & 1;
+        int x = min(xs0[j] + t, p.W0 - 1);
+        const unsigned char *row = tile + ly * p.in_pitch + (x - x_first);
+        float acc = p.kern[0] * (float)row[0];
+        for (int q = 1; q < ks; q++) acc += p.kern[q] * (float)row[q];
+        h1[(ly * p.txo + j) * 2 + t] = acc;
+    }
+    __syncthreads();
+
+    // column pass (centre, then symmetric pairs) at the two y positions, then the bilinear mix
+    for (int i = tid; i < noy * nox; i += 256) {
+        int oy = i / nox, ox = i - oy * nox;
+        float a1 = xa[ox], a0 = 1.f - a1, b1 = yb[oy], b0 = 1.f - b1;
+        float hrow[2];
+#pragma unroll
+        for (int yt = 0; yt < 2; yt++) {
+            int c = (yt ? ys1[oy] : ys0[oy]) - iy0;
+            float v[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (t == 1 && a1 == 0.f) { v[1] = 0.f; continue; }
+                const float *col = h1 + (c * p.txo + ox) * 2 + t;
+                float acc = p.kern[p.r] * col[0];
+                for (int m = 1; m <= p.r; m++)
+                    acc += p.kern[p.r + m] * (col[-m * p.txo * 2] + col[m * p.txo * 2]);
+                v[t] = acc;
+            }
+            hrow[yt] = (a1 == 0.f) ? v[0] : v[0] * a0 + v[1] * a1;
+        }
+        out[(size_t)(oy0 + oy) * p.w + ox0 + ox] = hrow[0] * b0 + hrow[1] * b1;
+    }
+}
+
+int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
+                       const LevelGeom &g, hipStream_t s)
+{
+    LevelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W0 = W0; a.H0 = H0; a.w = g.w; a.h = g.h;
+    a.r = g.ksize / 2;
+    if (g.ksize > 31) { set_error("blur kernel size %d > 31 unsupported", g.ksize); return OFC_EUNSUPPORTED; }
+    gaussian_kernel(g.ksize, g.sigma, a.kern);
+    a.sx = (double)W0 / g.w; a.sy = (double)H0 / g.h;
+    // output tile: big for the fine levels, small for the coarse ones (input footprint ~ scale)
+    if (a.sx <= 2.5) { a.txo = 64; a.tyo = 16; } else { a.txo = 32; a.tyo = 8; }
+    a.in_w = (int)(a.txo * a.sx) + 2 * a.r + 4;
+    a.in_h = (int)(a.tyo * a.sy) + 2 * a.r + 4;
+    a.in_pitch = (a.in_w + 3) & ~3;
+    size_t lds = (size_t)(2 * a.txo + 3 * a.tyo) * 4 + (size_t)a.in_h * 2 * a.txo * 4 +
+                 (size_t)a.in_h * a.in_pitch;
+    if (lds > 160 * 1024) { set_error("level_image tile needs %zu B LDS", lds); return OFC_EUNSUPPORTED; }
+    dim3 grid(cdiv(g.w, a.txo), cdiv(g.h, a.tyo), nimg);
+    hipLaunchKernelGGL(k_level_image, grid, dim3(256), lds, s, src, dst, a);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  polynomial expansion (the north-star kernel).  24 B/px algorithmic: 4 read + 20 written.
+//
+// Work-group = 256 threads = 4 waves, output tile 240 columns x rows_per_block rows, walked in
+// chunks of 16 rows:
+//   vertical pass   thread <-> column (250 = 240 + 2x5 halo columns, replicate-clamped), two groups of
+//                   8 rows; each thread loads 18 input values straight from global (lanes <-> x:
+//                   coalesced) and produces the three f32 moments t0,t1,t2 for 8 rows with the
+//                   symmetric / antisymmetric tap pairing of the reference -> LDS [3][16][252]
+//   horizontal pass wave <-> row, lane <-> 4 consecutive x: 12 ds_read_b128, f64 accumulators b1..b6 as
+//                   the reference, 5 float4 stores per lane (16 B/lane, 1 KiB/wave-instruction).
+// 48 KB LDS per work-group -> 3 work-groups per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int PE_N = 5;
+constexpr int PE_TX = 240;
+constexpr int PE_VW = PE_TX + 2 * PE_N;   // 250
+constexpr int PE_CH = 16;
+constexpr int PE_PITCH = 256;
+
+struct PolyArgs {
+    int W, H, rows_per_block;
+    float g[PE_N + 1], xg[PE_N + 1], xxg[PE_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+__global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
+                                                 PolyArgs p)
+{
+    __shared__ __align__(16) float t[3][PE_CH][PE_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = p.W, H = p.H;
+    const int x0 = blockIdx.x * PE_TX;
+    const int y_begin = blockIdx.y * p.rows_per_block;
+    const int y_end = min(y_begin + p.rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *img = I + (size_t)blockIdx.z * plane;
+    float *out = R + (size_t)blockIdx.z * 5 * plane;
+    const int xc = min(max(x0 - PE_N + tid, 0), W - 1);   // this thread's (clamped) column
+    const bool vec_ok = (W & 3) == 0;
+
+    for (int yc = y_begin; yc < y_end; yc += PE_CH) {
+        // ---- vertical pass ----
+        if (tid < PE_VW) {
+#pragma unroll
+            for (int rg = 0; rg < 2; rg++) {
+                const int yb = yc + 8 * rg;
+                float s[8 + 2 * PE_N];
+#pragma unroll
+                for (int j = 0; j < 8 + 2 * PE_N; j++) {
+                    int yy = min(max(yb - PE_N + j, 0), H - 1);
+                    s[j] = img[(size_t)yy * W + xc];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float t0 = s[i + PE_N] * p.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int k = 1; k <= PE_N; k++) {
+                        float a = s[i + PE_N - k], b = s[i + PE_N + k];
+                        float pp = a + b;
+                        t0 = fmaf(p.g[k], pp, t0);
+                        t1 = fmaf(p.xg[k], b - a, t1);
+                        t2 = fmaf(p.xxg[k], pp, t2);
+                    }
+                    t[0][8 * rg + i][tid] = t0;
+                    t[1][8 * rg + i][tid] = t1;
+                    t[2][8 * rg + i][tid] = t2;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- horizontal pass ----
+        for (int rr = wave; rr < PE_CH; rr += 4) {
+            const int y = yc + rr;
+            if (y >= y_end) break;
+            const int xo = x0 + 4 * lane;
+            if (lane < PE_TX / 4 && xo < W) {
+                float a0[16], a1[16], a2[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float4 v0 = *reinterpret_cast<const float4 *>(&t[0][rr][4 * lane + 4 * q]);
+                    float4 v1 = *reinterpret_cast<const float4 *>(&t[1][rr][4 * lane + 4 * q]);
+                    float4 v2 = *reinterpret_cast<const float4 *>(&t[2][rr][4 * lane + 4 * q]);
+                    a0[4 * q] = v0.x; a0[4 * q + 1] = v0.y; a0[4 * q + 2] = v0.z; a0[4 * q + 3] = v0.w;
+                    a1[4 * q] = v1.x; a1[4 * q + 1] = v1.y; a1[4 * q + 2] = v1.z; a1[4 * q + 3] = v1.w;
+                    a2[4 * q] = v2.x; a2[4 * q + 1] = v2.y; a2[4 * q + 2] = v2.z; a2[4 * q + 3] = v2.w;
+                }
+                float r0[4], r1[4], r2[4], r3[4], r4[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int c = o + PE_N;
+                    double b1 = (double)(a0[c] * p.g[0]), b2 = 0, b3 = (double)(a1[c] * p.g[0]),
+                           b4 = 0, b5 = (double)(a2[c] * p.g[0]), b6 = 0;
+#pragma unroll
+                    for (int k = 1; k <= PE_N; k++) {
+                        double tg = (double)(a0[c + k] + a0[c - k]);
+                        b1 = fma(tg, (double)p.g[k], b1);
+                        b4 = fma(tg, (double)p.xxg[k], b4);
+                        b2 += (double)((a0[c + k] - a0[c - k]) * p.xg[k]);
+                        b3 += (double)((a1[c + k] + a1[c - k]) * p.g[k]);
+                        b6 += (double)((a1[c + k] - a1[c - k]) * p.xg[k]);
+                        b5 += (double)((a2[c + k] + a2[c - k]) * p.g[k]);
+                    }
+                    r1[o] = (float)(b2 * p.ig11);
+                    r0[o] = (float)(b3 * p.ig11);
+                    r3[o] = (float)(b1 * p.ig03 + b4 * p.ig33);
+                    r2[o] = (float)(b1 * p.ig03 + b5 * p.ig33);
+                    r4[o] = (float)(b6 * p.ig55);
+                }
+                float *o0 = out + (size_t)y * W + xo;
+                if (vec_ok) {   // W % 4 == 0 -> xo+3 < W and 16-B aligned
+                    *reinterpret_cast<float4 *>(o0) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+                    *reinterpret_cast<float4 *>(o0 + plane) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+                    *reinterpret_cast<float4 *>(o0 + 2 * plane) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+                    *reinterpret_cast<float4 *>(o0 + 3 * plane) = make_float4(r3[0], r3[1], r3[2], r3[3]);
+                    *reinterpret_cast<float4 *>(o0 + 4 * plane) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                        if (xo + o < W) {
+                            o0[o] = r0[o]; o0[plane + o] = r1[o]; o0[2 * plane + o] = r2[o];
+                            o0[3 * plane + o] = r3[o]; o0[4 * plane + o] = r4[o];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int polyexp_default_rows(int W, int H, int nimg)
+{
+    int tiles_x = cdiv(W, PE_TX);
+    int rows = 64;
+    while (rows > PE_CH && (int64_t)tiles_x * cdiv(H, rows) * nimg < 2048) rows >>= 1;
+    return rows;
+}
+
+int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
+                   int rows_per_block, hipStream_t s)
+{
+    PolyArgs a;
+    a.W = W; a.H = H;
+    if (rows_per_block <= 0) rows_per_block = polyexp_default_rows(W, H, nimg);
+    a.rows_per_block = cdiv(rows_per_block, PE_CH) * PE_CH;
+    for (int i = 0; i <= PE_N; i++) { a.g[i] = c.g[i]; a.xg[i] = c.xg[i]; a.xxg[i] = c.xxg[i]; }
+    a.ig11 = c.ig11; a.ig03 = c.ig03; a.ig33 = c.ig33; a.ig55 = c.ig55;
+    dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
+    hipLaunchKernelGGL(k_polyexp, grid, dim3(256), 0, s, I, R, a);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  update matrices: bilinear warp-sample of R1 at x+flow, G/h products, border attenuation.
+// 68 B/px algorithmic (20 R0 + 20 R1 + 8 flow read, 20 M written); gather-coalesced because the
+// flow is smooth.  Contraction off: bit-exact with the oracle.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R0b,
+                                                         const float *__restrict__ R1b,
+                                                         size_t pair_stride_R,
+                                                         const float *__restrict__ flowb,
+                                                         float *__restrict__ Mb, int W, int H)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)W * H;
+    const float *R0 = R0b + blockIdx.z * pair_stride_R;
+    const float *R1 = R1b + blockIdx.z * pair_stride_R;
+    const float2 fl = reinterpret_cast<const float2 *>(flowb)[(size_t)blockIdx.z * plane + (size_t)y * W + x];
+    float *M = Mb + (size_t)blockIdx.z * 5 * plane;
+    const size_t idx = (size_t)y * W + x;
+    const float dx = fl.x, dy = fl.y;
+    float fx = (float)x + dx, fy = (float)y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    fx -= (float)x1; fy -= (float)y1;
+    float r2, r3, r4, r5, r6;
+    const float R00 = R0[idx], R01 = R0[plane + idx], R02 = R0[2 * plane + idx],
+                R03 = R0[3 * plane + idx], R04 = R0[4 * plane + idx];
+    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
+                    a11 = fx * fy;
+        const float *p = R1 + (size_t)y1 * W + x1;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1];
+        r4 = (R02 + r4) * 0.5f;
+        r5 = (R03 + r5) * 0.5f;
+        r6 = (R04 + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R02; r5 = R03; r6 = R04 * 0.5f;
+    }
+    r2 = (R00 - r2) * 0.5f;
+    r3 = (R01 - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    constexpr int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(W - BORDER * 2) ||
+        (unsigned)(y - BORDER) >= (unsigned)(H - BORDER * 2)) {
+        // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} (select form: no dynamically indexed array)
+        auto bw = [](int i) { return i < 2 ? 0.14f : 0.4472f; };
+        float scale = (x < BORDER ? bw(x) : 1.f) * (x >= W - BORDER ? bw(W - x - 1) : 1.f) *
+                      (y < BORDER ? bw(y) : 1.f) * (y >= H - BORDER ? bw(H - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    M[idx] = r4 * r4 + r6 * r6;
+    M[plane + idx] = (r4 + r5) * r6;
+    M[2 * plane + idx] = r5 * r5 + r6 * r6;
+    M[3 * plane + idx] = r4 * r2 + r6 * r3;
+    M[4 * plane + idx] = r6 * r2 + r5 * r3;
+}
+
+int launch_update_matrices(const float *R0, const float *R1, size_t pair_stride_R,
+                           const float *flow, float *M, int npair, int W, int H, hipStream_t s)
+{
+    dim3 grid(cdiv(W, 256), H, npair);
+    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, s, R0, R1, pair_stride_R, flow, M, W, H);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  box mean (winsize x winsize, replicate border) of the 5 M planes + regularised 2x2 solve.
+// 28 B/px algorithmic (20 read + 8 written).
+//
+// "Column march": work-group = 256 threads <-> 256 columns (256 - 2m outputs + halo), marching down a
+// strip of rows.  Every thread keeps the vertical (2m+1)-row sums of its column for the 5 channels as
+// f64 running sums in registers (+ new row - old row: 2 loads per channel per row, L2-resident), and
+// every 4 rows the work-group exchanges them through LDS (41 KB -> 3 work-groups per CU) so
+// that wave <-> row, lane <-> 4 consecutive x can form the horizontal sums by sliding (2m+1 + 3*2 adds
+// for 4 outputs) from 9 ds_read_b128 per channel, solve, and store 4 float2.  The sums are exact f64
+// sums of f32 values (the reference's running sums round the f32 differences: ~1e-7 relative).
+// ------------------------------------------------------------------------------------------------
+constexpr int BS_ROWS = 4;
+
+template <int M>
+__global__ __launch_bounds__(256) void k_box_solve(const float *__restrict__ Mb,
+                                                   float *__restrict__ flowb, int W, int H,
+                                                   int rows_per_block)
+{
+    constexpr int TXO = 256 - 2 * M;          // outputs per work-group row
+    constexpr int NV = 2 * M + 4;             // vsum values a lane needs for its 4 outputs
+    constexpr int NV2 = (NV + 1) / 2;         // as double2 reads
+    constexpr int PITCH = 256 + 2;            // doubles; keeps rows 16-B aligned
+    __shared__ __align__(16) double vs[5][BS_ROWS][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TXO;
+    const int y_begin = blockIdx.y * rows_per_block;
+    const int y_end = min(y_begin + rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *Mp = Mb + (size_t)blockIdx.z * 5 * plane;
+    float2 *flow = reinterpret_cast<float2 *>(flowb) + (size_t)blockIdx.z * plane;
+    const int xc = min(max(x0 - M + tid, 0), W - 1);
+    const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+
+    // vertical sums of rows [y_begin-M, y_begin+M] (replicate)
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int j = -M; j <= M; j++) {
+        const size_t o = (size_t)min(max(y_begin + j, 0), H - 1) * W + xc;
+#pragma unroll
+        for (int c = 0; c < 5; c++) v[c] += (double)Mp[c * plane + o];
+    }
+    for (int yc = y_begin; yc < y_end; yc += BS_ROWS) {
+#pragma unroll
+        for (int r = 0; r < BS_ROWS; r++) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) vs[c][r][tid] = v[c];
+            // advance to row yc + r + 1
+            const int y = yc + r;
+            const size_t oa = (size_t)min(y + 1 + M, H - 1) * W + xc;
+            const size_t os = (size_t)max(y - M, 0) * W + xc;
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+                v[c] += (double)Mp[c * plane + oa] - (double)Mp[c * plane + os];
+        }
+        __syncthreads();
+        const int y = yc + wave;
+        const int xo = x0 + 4 * lane;
+        if (y < y_end && 4 * lane < TXO && xo < W) {
+            double S[5][4];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double a[2 * NV2];
+#pragma unroll
+                for (int q = 0; q < NV2; q++) {
+                    double2 d = *reinterpret_cast<const double2 *>(&vs[c][wave][4 * lane + 2 * q]);
+                    a[2 * q] = d.x; a[2 * q + 1] = d.y;
+                }
+                double s = a[0];
+#pragma unroll
+                for (int q = 1; q <= 2 * M; q++) s += a[q];
+                S[c][0] = s;
+#pragma unroll
+                for (int o = 1; o < 4; o++) {
+                    s += a[2 * M + o] - a[o - 1];
+                    S[c][o] = s;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (4 * lane + o < TXO && xo + o < W) {
+                    const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                 h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    flow[(size_t)y * W + xo + o] = make_float2((float)((g11 * h2 - g12 * h1) * idet),
+                                                               (float)((g22 * h1 - g12 * h2) * idet));
+                }
+            }
+        }
+        __syncthreads();   // vs is rewritten by the next step
+    }
+}
+
+int box_default_rows(int W, int H, int npair)
+{
+    int tiles_x = cdiv(W, 256 - 14);
+    int rows = 128;
+    while (rows > 16 && (int64_t)tiles_x * cdiv(H, rows) * npair < 1536) rows >>= 1;
+    return rows;
+}
+
+int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int winsize,
+                     int rows_per_block, hipStream_t s)
+{
+    if (rows_per_block <= 0) rows_per_block = box_default_rows(W, H, npair);
+    rows_per_block = cdiv(rows_per_block, BS_ROWS) * BS_ROWS;
+    dim3 block(256);
+#define OFC_BOX_CASE(MM)                                                                         \
+    case 2 * MM + 1: {                                                                           \
+        dim3 grid(cdiv(W, 256 - 2 * MM), cdiv(H, rows_per_block), npair);                        \
+        hipLaunchKernelGGL(k_box_solve<MM>, grid, block, 0, s, M, flow, W, H, rows_per_block);   \
+        break;                                                                                   \
+    }
+    switch (winsize) {
+        OFC_BOX_CASE(2)
+        OFC_BOX_CASE(3)
+        OFC_BOX_CASE(4)
+        OFC_BOX_CASE(5)
+        OFC_BOX_CASE(6)
+        OFC_BOX_CASE(7)
+        OFC_BOX_CASE(8)
+    default:
+        set_error("winsize %d unsupported (odd 5..17)", winsize);
+        return OFC_EUNSUPPORTED;
+    }
+#undef OFC_BOX_CASE
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  flow upsample: resize(prevFlow, (w,h), INTER_LINEAR) * (1/pyr_scale).  10 B/px.  Bit-exact.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_resize(const float2 *__restrict__ src,
+                                                     float2 *__restrict__ dst, int sw, int sh, int dw,
+                                                     int dh, double scx, double scy, float mul)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const float2 *s = src + (size_t)blockIdx.z * sw * sh;
+    float2 *d = dst + (size_t)blockIdx.z * dw * dh;
+    if (sw == dw && sh == dh) {
+        float2 v = s[(size_t)y * sw + x];
+        d[(size_t)y * dw + x] = make_float2(v.x * mul, v.y * mul);
+        return;
+    }
+    int sx0, sy0, sy1;
+    float a1, b1;
+    lin_tap_x(x, scx, sw, sx0, a1);
+    lin_tap_y(y, scy, sh, sy0, sy1, b1);
+    const float a0 = 1.f - a1, b0 = 1.f - b1;
+    const int sx1 = (a1 == 0.f) ? sx0 : sx0 + 1;
+    const float2 p00 = s[(size_t)sy0 * sw + sx0], p01 = s[(size_t)sy0 * sw + sx1];
+    const float2 p10 = s[(size_t)sy1 * sw + sx0], p11 = s[(size_t)sy1 * sw + sx1];
+    float h0x, h0y, h1x, h1y;
+    if (a1 == 0.f) {
+        h0x = p00.x; h0y = p00.y; h1x = p10.x; h1y = p10.y;
+    } else {
+        h0x = p00.x * a0 + p01.x * a1; h0y = p00.y * a0 + p01.y * a1;
+        h1x = p10.x * a0 + p11.x * a1; h1y = p10.y * a0 + p11.y * a1;
+    }
+    d[(size_t)y * dw + x] = make_float2((h0x * b0 + h1x * b1) * mul, (h0y * b0 + h1y * b1) * mul);
+}
+
+int launch_flow_resize(const float *src, float *dst, int npair, int sw, int sh, int dw, int dh,
+                       float mul, hipStream_t s)
+{
+    dim3 grid(cdiv(dw, 256), dh, npair);
+    hipLaunchKernelGGL(k_flow_resize, grid, dim3(256), 0, s, reinterpret_cast<const float2 *>(src),
+                       reinterpret_cast<float2 *>(dst), sw, sh, dw, dh, (double)sw / dw,
+                       (double)sh / dh, mul);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+}  // namespace ofc

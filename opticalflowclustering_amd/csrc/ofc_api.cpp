@@ -1,0 +1,516 @@
+// ofc_api.cpp -- C ABI of libofc.so, part 1: runtime plumbing and the Farneback flow engine.
+// Declared in include/ofc.h (which cites the reference call each entry point replaces).
+#include "ofc_common.h"
+
+#include <cfloat>
+#include <cmath>
+#include <memory>
+
+namespace ofc {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int ensure_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable GPU (hipGetDeviceCount: %s, count %d); libofc has no CPU fallback",
+                  hipGetErrorString(e), n);
+        return OFC_ENODEV;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return OFC_ENODEV;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return OFC_ENODEV;
+    }
+    return OFC_OK;
+}
+
+// ---- geometry & constants (host) ----
+int pyramid_levels(int W, int H, const ofc_fb_params &p)
+{
+    const int min_size = 32;
+    int k;
+    double scale = 1;
+    for (k = 0; k < p.levels; k++) {
+        scale *= p.pyr_scale;
+        if (W * scale < min_size || H * scale < min_size) break;
+    }
+    return k;
+}
+
+LevelGeom level_geometry(int W, int H, const ofc_fb_params &p, int k)
+{
+    double scale = 1;
+    for (int i = 0; i < k; i++) scale *= p.pyr_scale;
+    LevelGeom g;
+    g.sigma = (1. / scale - 1) * 0.5;
+    int sz = (int)std::nearbyint(g.sigma * 5) | 1;   // cvRound: half to even
+    g.ksize = sz < 3 ? 3 : sz;
+    g.w = (int)std::nearbyint(W * scale);
+    g.h = (int)std::nearbyint(H * scale);
+    return g;
+}
+
+void gaussian_kernel(int n, double sigma, float *k)
+{
+    static const float tab[4][7] = {{1.f},
+                                    {0.25f, 0.5f, 0.25f},
+                                    {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                    {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float *fixed = (n % 2 == 1 && n <= 7 && sigma <= 0) ? tab[n >> 1] : nullptr;
+    double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2X = -0.5 / (sigmaX * sigmaX), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = fixed ? (double)fixed[i] : std::exp(scale2X * x * x);
+        k[i] = (float)t;
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] = (float)(k[i] * sum);
+}
+
+void polyexp_setup(int n, double sigma, PolyConsts &c)
+{
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    std::vector<float> gf(2 * n + 1);
+    double s = 0;
+    for (int x = -n; x <= n; x++) {
+        gf[x + n] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += gf[x + n];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) gf[x + n] = (float)(gf[x + n] * s);
+    memset(&c, 0, sizeof(c));
+    for (int x = 0; x <= n && x < 8; x++) {
+        c.g[x] = gf[x + n];
+        c.xg[x] = (float)(x * c.g[x]);
+        c.xxg[x] = (float)(x * x * c.g[x]);
+    }
+    double G00 = 0, G11 = 0, G33 = 0, G55 = 0;
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            float gg = gf[y + n] * gf[x + n];
+            G00 += gg;
+            G11 += gg * x * x;
+            G33 += gg * x * x * x * x;
+            G55 += gg * x * x * y * y;
+        }
+    double a = G00, b = G11, cc = G33, e = G55;
+    double det = a * (cc * cc - e * e) - 2 * b * b * (cc - e);
+    c.ig11 = 1. / G11;
+    c.ig03 = -b * (cc - e) / det;
+    c.ig33 = (a * cc - b * b) / det;
+    c.ig55 = 1. / G55;
+}
+
+static int check_params(const ofc_fb_params &p, int W, int H)
+{
+    OFC_REQUIRE(W >= 16 && H >= 16 && W <= 16384 && H <= 16384, "frame size %dx%d out of range", W, H);
+    OFC_REQUIRE(p.pyr_scale > 0 && p.pyr_scale < 1, "pyr_scale must be in (0,1)");
+    OFC_REQUIRE(p.levels >= 0 && p.levels <= 16, "levels out of range");
+    OFC_REQUIRE(p.iterations >= 1 && p.iterations <= 64, "iterations out of range");
+    if (p.flags != 0) {
+        set_error("flags=%d: only the box-filter variant (flags 0) the reference uses is implemented", p.flags);
+        return OFC_EUNSUPPORTED;
+    }
+    if (p.poly_n != 5) {
+        set_error("poly_n=%d: the polyexp kernel is specialised for poly_n=5 (the reference's value)", p.poly_n);
+        return OFC_EUNSUPPORTED;
+    }
+    return OFC_OK;
+}
+
+}  // namespace ofc
+
+using namespace ofc;
+
+// =================================================================================================
+// plumbing
+// =================================================================================================
+extern "C" {
+
+int ofc_version(void) { return OFC_VERSION; }
+const char *ofc_last_error(void) { return g_err.c_str(); }
+
+int ofc_device_count(int *n)
+{
+    OFC_REQUIRE(n, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return OFC_OK;
+}
+
+int ofc_malloc(int device, size_t bytes, void **dptr)
+{
+    OFC_REQUIRE(dptr, "null pointer");
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipMalloc(dptr, bytes));
+    return OFC_OK;
+}
+
+int ofc_free(int device, void *dptr)
+{
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipFree(dptr));
+    return OFC_OK;
+}
+
+int ofc_memcpy_h2d(int device, void *dst, const void *src, size_t bytes)
+{
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return OFC_OK;
+}
+
+int ofc_memcpy_d2h(int device, void *dst, const void *src, size_t bytes)
+{
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_memset(int device, void *dst, int value, size_t bytes)
+{
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipMemset(dst, value, bytes));
+    return OFC_OK;
+}
+
+int ofc_device_sync(int device)
+{
+    OFC_TRY(ensure_device(device));
+    OFC_HIP(hipDeviceSynchronize());
+    return OFC_OK;
+}
+
+void ofc_fb_default_params(ofc_fb_params *p)
+{
+    if (!p) return;
+    p->pyr_scale = 0.5; p->levels = 3; p->winsize = 15; p->iterations = 3;
+    p->poly_n = 5; p->poly_sigma = 1.2; p->flags = 0;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// flow engine
+// =================================================================================================
+struct ofc_flow {
+    int device = 0, W = 0, H = 0, max_batch = 0, levels = 0;
+    ofc_fb_params prm{};
+    PolyConsts pc{};
+    std::vector<LevelGeom> geom;    // [0..levels]
+    hipStream_t stream = nullptr;
+    DevBuf I, R, M, flowA, flowB;   // scratch sized for level 0 and max_batch
+    DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
+    DevBuf prev_gray;               // streaming state
+    bool have_prev = false;
+};
+
+namespace ofc {
+
+static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float *flow_dev)
+{
+    const int npair = n_frames - 1;
+    const int W = f->W, H = f->H;
+    const size_t P0 = (size_t)W * H;
+    hipStream_t s = f->stream;
+    float *I = f->I.as<float>(), *R = f->R.as<float>(), *M = f->M.as<float>();
+    float *prevFlow = nullptr;
+    int pw = 0, ph = 0;
+    for (int k = f->levels; k >= 0; k--) {
+        const LevelGeom &g = f->geom[k];
+        const size_t P = (size_t)g.w * g.h;
+        // level-k flow lives in flowA/flowB alternately; level 0 goes straight to the caller
+        float *flow = (k == 0) ? flow_dev : (((f->levels - k) & 1) ? f->flowB.as<float>() : f->flowA.as<float>());
+        if (!prevFlow) {
+            OFC_HIP(hipMemsetAsync(flow, 0, sizeof(float) * 2 * P * npair, s));
+        } else {
+            OFC_TRY(launch_flow_resize(prevFlow, flow, npair, pw, ph, g.w, g.h,
+                                       (float)(1. / f->prm.pyr_scale), s));
+        }
+        OFC_TRY(launch_level_image(frames_dev, I, n_frames, W, H, g, s));
+        OFC_TRY(launch_polyexp(I, R, n_frames, g.w, g.h, f->pc, 0, s));
+        const size_t strideR = 5 * P;
+        OFC_TRY(launch_update_matrices(R, R + strideR, strideR, flow, M, npair, g.w, g.h, s));
+        for (int i = 0; i < f->prm.iterations; i++) {
+            OFC_TRY(launch_box_solve(M, flow, npair, g.w, g.h, f->prm.winsize, 0, s));
+            if (i < f->prm.iterations - 1)
+                OFC_TRY(launch_update_matrices(R, R + strideR, strideR, flow, M, npair, g.w, g.h, s));
+        }
+        prevFlow = flow;
+        pw = g.w; ph = g.h;
+        (void)P0;
+    }
+    return OFC_OK;
+}
+
+}  // namespace ofc
+
+extern "C" {
+
+int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_batch, ofc_flow_t **out)
+{
+    OFC_REQUIRE(out, "null out pointer");
+    *out = nullptr;
+    ofc_fb_params prm;
+    if (p) prm = *p; else ofc_fb_default_params(&prm);
+    OFC_TRY(check_params(prm, W, H));
+    OFC_REQUIRE(max_batch >= 1 && max_batch <= 4096, "max_batch out of range");
+    OFC_REQUIRE((prm.winsize & 1) && prm.winsize >= 5, "winsize must be odd and >= 5");
+    OFC_TRY(ensure_device(device));
+    std::unique_ptr<ofc_flow> f(new ofc_flow);
+    f->device = device; f->W = W; f->H = H; f->max_batch = max_batch; f->prm = prm;
+    f->levels = pyramid_levels(W, H, prm);
+    for (int k = 0; k <= f->levels; k++) f->geom.push_back(level_geometry(W, H, prm, k));
+    polyexp_setup(prm.poly_n, prm.poly_sigma, f->pc);
+    OFC_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    const size_t P0 = (size_t)W * H, nb = (size_t)max_batch;
+    OFC_TRY(f->I.alloc(sizeof(float) * P0 * (nb + 1)));
+    OFC_TRY(f->R.alloc(sizeof(float) * 5 * P0 * (nb + 1)));
+    OFC_TRY(f->M.alloc(sizeof(float) * 5 * P0 * nb));
+    const size_t P1 = f->levels >= 1 ? (size_t)f->geom[1].w * f->geom[1].h : 1;
+    OFC_TRY(f->flowA.alloc(sizeof(float) * 2 * P1 * nb));
+    OFC_TRY(f->flowB.alloc(sizeof(float) * 2 * P1 * nb));
+    OFC_TRY(f->frames2.alloc(2 * P0));
+    OFC_TRY(f->flow1.alloc(sizeof(float) * 2 * P0));
+    OFC_TRY(f->prev_gray.alloc(P0));
+    *out = f.release();
+    return OFC_OK;
+}
+
+void ofc_flow_destroy(ofc_flow_t *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->stream) {
+        (void)hipStreamSynchronize(f->stream);
+        (void)hipStreamDestroy(f->stream);
+    }
+    delete f;
+}
+
+int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames, float *flow_dev)
+{
+    OFC_REQUIRE(f && frames_dev && flow_dev, "null pointer");
+    OFC_REQUIRE(n_frames >= 2 && n_frames - 1 <= f->max_batch, "n_frames-1 = %d pairs not in [1, max_batch=%d]",
+                n_frames - 1, f->max_batch);
+    OFC_TRY(ensure_device(f->device));
+    return flow_run(f, frames_dev, n_frames, flow_dev);
+}
+
+int ofc_flow_sync(ofc_flow_t *f)
+{
+    OFC_REQUIRE(f, "null pointer");
+    OFC_TRY(ensure_device(f->device));
+    OFC_HIP(hipStreamSynchronize(f->stream));
+    return OFC_OK;
+}
+
+int ofc_flow_calc(ofc_flow_t *f, const uint8_t *prev_gray, const uint8_t *next_gray, float *flow_out)
+{
+    OFC_REQUIRE(f && prev_gray && next_gray && flow_out, "null pointer");
+    OFC_TRY(ensure_device(f->device));
+    const size_t P0 = (size_t)f->W * f->H;
+    uint8_t *fr = f->frames2.as<uint8_t>();
+    OFC_HIP(hipMemcpyAsync(fr, prev_gray, P0, hipMemcpyHostToDevice, f->stream));
+    OFC_HIP(hipMemcpyAsync(fr + P0, next_gray, P0, hipMemcpyHostToDevice, f->stream));
+    OFC_TRY(flow_run(f, fr, 2, f->flow1.as<float>()));
+    OFC_HIP(hipMemcpyAsync(flow_out, f->flow1.p, sizeof(float) * 2 * P0, hipMemcpyDeviceToHost, f->stream));
+    OFC_HIP(hipStreamSynchronize(f->stream));
+    return OFC_OK;
+}
+
+int ofc_flow_push_gray(ofc_flow_t *f, const uint8_t *gray, float *flow_out)
+{
+    OFC_REQUIRE(f && gray, "null pointer");
+    OFC_TRY(ensure_device(f->device));
+    const size_t P0 = (size_t)f->W * f->H;
+    uint8_t *fr = f->frames2.as<uint8_t>();
+    if (!f->have_prev) {
+        OFC_HIP(hipMemcpyAsync(f->prev_gray.p, gray, P0, hipMemcpyHostToDevice, f->stream));
+        OFC_HIP(hipStreamSynchronize(f->stream));
+        f->have_prev = true;
+        set_error("first frame pushed: no pair yet");
+        return OFC_ENOTREADY;
+    }
+    OFC_REQUIRE(flow_out, "null flow_out");
+    OFC_HIP(hipMemcpyAsync(fr, f->prev_gray.p, P0, hipMemcpyDeviceToDevice, f->stream));
+    OFC_HIP(hipMemcpyAsync(fr + P0, gray, P0, hipMemcpyHostToDevice, f->stream));
+    OFC_HIP(hipMemcpyAsync(f->prev_gray.p, fr + P0, P0, hipMemcpyDeviceToDevice, f->stream));
+    OFC_TRY(flow_run(f, fr, 2, f->flow1.as<float>()));
+    OFC_HIP(hipMemcpyAsync(flow_out, f->flow1.p, sizeof(float) * 2 * P0, hipMemcpyDeviceToHost, f->stream));
+    OFC_HIP(hipStreamSynchronize(f->stream));
+    return OFC_OK;
+}
+
+// =================================================================================================
+// single stages (host buffers; parity-test hooks).  Interleaved <-> planar conversion on the host.
+// =================================================================================================
+static void interleave5(const float *planar, size_t P, float *inter)
+{
+    for (int c = 0; c < 5; c++)
+        for (size_t i = 0; i < P; i++) inter[i * 5 + c] = planar[c * P + i];
+}
+static void planarize5(const float *inter, size_t P, float *planar)
+{
+    for (int c = 0; c < 5; c++)
+        for (size_t i = 0; i < P; i++) planar[c * P + i] = inter[i * 5 + c];
+}
+
+int ofc_level_image(int device, const uint8_t *gray, int W, int H, const ofc_fb_params *p, int k,
+                    float *out, int *w_out, int *h_out)
+{
+    OFC_REQUIRE(gray && out, "null pointer");
+    ofc_fb_params prm;
+    if (p) prm = *p; else ofc_fb_default_params(&prm);
+    OFC_TRY(check_params(prm, W, H));
+    OFC_REQUIRE(k >= 0 && k <= pyramid_levels(W, H, prm), "level %d out of range", k);
+    OFC_TRY(ensure_device(device));
+    LevelGeom g = level_geometry(W, H, prm, k);
+    DevBuf src, dst;
+    OFC_TRY(src.alloc((size_t)W * H));
+    OFC_TRY(dst.alloc(sizeof(float) * g.w * g.h));
+    OFC_HIP(hipMemcpy(src.p, gray, (size_t)W * H, hipMemcpyHostToDevice));
+    OFC_TRY(launch_level_image(src.as<uint8_t>(), dst.as<float>(), 1, W, H, g, nullptr));
+    OFC_HIP(hipMemcpy(out, dst.p, sizeof(float) * g.w * g.h, hipMemcpyDeviceToHost));
+    if (w_out) *w_out = g.w;
+    if (h_out) *h_out = g.h;
+    return OFC_OK;
+}
+
+int ofc_polyexp(int device, const float *img, int W, int H, int n, double sigma, float *R5)
+{
+    OFC_REQUIRE(img && R5, "null pointer");
+    OFC_REQUIRE(W >= 1 && H >= 1, "bad size");
+    if (n != 5) { set_error("poly_n=%d unsupported (kernel specialised for 5)", n); return OFC_EUNSUPPORTED; }
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    PolyConsts pc;
+    polyexp_setup(n, sigma, pc);
+    DevBuf I, R;
+    OFC_TRY(I.alloc(sizeof(float) * P));
+    OFC_TRY(R.alloc(sizeof(float) * 5 * P));
+    OFC_HIP(hipMemcpy(I.p, img, sizeof(float) * P, hipMemcpyHostToDevice));
+    OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), 1, W, H, pc, 0, nullptr));
+    std::vector<float> planar(5 * P);
+    OFC_HIP(hipMemcpy(planar.data(), R.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));
+    interleave5(planar.data(), P, R5);
+    return OFC_OK;
+}
+
+int ofc_update_matrices(int device, const float *R0, const float *R1, const float *flow, int W, int H,
+                        float *M)
+{
+    OFC_REQUIRE(R0 && R1 && flow && M, "null pointer");
+    OFC_REQUIRE(W >= 2 && H >= 2, "bad size");
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    std::vector<float> tmp(10 * P);
+    planarize5(R0, P, tmp.data());
+    planarize5(R1, P, tmp.data() + 5 * P);
+    DevBuf dR, dF, dM;
+    OFC_TRY(dR.alloc(sizeof(float) * 10 * P));
+    OFC_TRY(dF.alloc(sizeof(float) * 2 * P));
+    OFC_TRY(dM.alloc(sizeof(float) * 5 * P));
+    OFC_HIP(hipMemcpy(dR.p, tmp.data(), sizeof(float) * 10 * P, hipMemcpyHostToDevice));
+    OFC_HIP(hipMemcpy(dF.p, flow, sizeof(float) * 2 * P, hipMemcpyHostToDevice));
+    OFC_TRY(launch_update_matrices(dR.as<float>(), dR.as<float>() + 5 * P, 5 * P, dF.as<float>(),
+                                   dM.as<float>(), 1, W, H, nullptr));
+    OFC_HIP(hipMemcpy(tmp.data(), dM.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));
+    interleave5(tmp.data(), P, M);
+    return OFC_OK;
+}
+
+int ofc_box_solve(int device, const float *M, int W, int H, int winsize, float *flow)
+{
+    OFC_REQUIRE(M && flow, "null pointer");
+    OFC_REQUIRE(W >= 1 && H >= 1, "bad size");
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    std::vector<float> tmp(5 * P);
+    planarize5(M, P, tmp.data());
+    DevBuf dM, dF;
+    OFC_TRY(dM.alloc(sizeof(float) * 5 * P));
+    OFC_TRY(dF.alloc(sizeof(float) * 2 * P));
+    OFC_HIP(hipMemcpy(dM.p, tmp.data(), sizeof(float) * 5 * P, hipMemcpyHostToDevice));
+    OFC_TRY(launch_box_solve(dM.as<float>(), dF.as<float>(), 1, W, H, winsize, 0, nullptr));
+    OFC_HIP(hipMemcpy(flow, dF.p, sizeof(float) * 2 * P, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_flow_resize(int device, const float *flow, int sw, int sh, int dw, int dh, float mul, float *out)
+{
+    OFC_REQUIRE(flow && out, "null pointer");
+    OFC_REQUIRE(sw >= 1 && sh >= 1 && dw >= 1 && dh >= 1, "bad size");
+    OFC_TRY(ensure_device(device));
+    DevBuf s, d;
+    OFC_TRY(s.alloc(sizeof(float) * 2 * sw * sh));
+    OFC_TRY(d.alloc(sizeof(float) * 2 * dw * dh));
+    OFC_HIP(hipMemcpy(s.p, flow, sizeof(float) * 2 * sw * sh, hipMemcpyHostToDevice));
+    OFC_TRY(launch_flow_resize(s.as<float>(), d.as<float>(), 1, sw, sh, dw, dh, mul, nullptr));
+    OFC_HIP(hipMemcpy(out, d.p, sizeof(float) * 2 * dw * dh, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+// bench hook: polyexp over n_images distinct resident images, HIP events on the launch stream
+int ofc_bench_polyexp(int device, int W, int H, int n_images, int iters, int rows_per_block,
+                      float *ms_per_launch)
+{
+    OFC_REQUIRE(ms_per_launch && n_images >= 1 && iters >= 1, "bad arguments");
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    PolyConsts pc;
+    polyexp_setup(5, 1.2, pc);
+    DevBuf I, R;
+    OFC_TRY(I.alloc(sizeof(float) * P * n_images));
+    OFC_TRY(R.alloc(sizeof(float) * 5 * P * n_images));
+    {   // non-trivial, image-dependent content (random-ish texture), generated on the host once
+        std::vector<float> h(P);
+        uint32_t st = 12345u;
+        for (int im = 0; im < n_images; im++) {
+            for (size_t i = 0; i < P; i++) {
+                st = st * 1664525u + 1013904223u;
+                h[i] = (float)(st >> 24);
+            }
+            OFC_HIP(hipMemcpy(I.as<float>() + (size_t)im * P, h.data(), sizeof(float) * P, hipMemcpyHostToDevice));
+        }
+    }
+    hipStream_t s;
+    OFC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    OFC_HIP(hipEventCreate(&e0));
+    OFC_HIP(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s));
+    OFC_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s));
+    OFC_HIP(hipEventRecord(e1, s));
+    OFC_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    OFC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    return OFC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+"""numpy-level access to the individual Farneback stages of libofc (parity-test and bench hooks).
+Layouts are OpenCV's internal interleaved ones so results compare 1:1 with the oracle."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FbParams, check, load, ptr
+
+
+def level_image(gray, k, params=None, device=0):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    p = params or FbParams()
+    out = np.empty((H, W), np.float32)
+    w, h = C.c_int(), C.c_int()
+    check(load().ofc_level_image(device, ptr(gray), W, H, C.byref(p), k, ptr(out), C.byref(w), C.byref(h)))
+    return out.reshape(-1)[: w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def polyexp(img, n=5, sigma=1.2, device=0):
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape
+    out = np.empty((H, W, 5), np.float32)
+    check(load().ofc_polyexp(device, ptr(img), W, H, n, sigma, ptr(out)))
+    return out
+
+
+def update_matrices(R0, R1, flow, device=0):
+    R0, R1, flow = (np.ascontiguousarray(a, np.float32) for a in (R0, R1, flow))
+    H, W = flow.shape[:2]
+    M = np.empty((H, W, 5), np.float32)
+    check(load().ofc_update_matrices(device, ptr(R0), ptr(R1), ptr(flow), W, H, ptr(M)))
+    return M
+
+
+def box_solve(M, winsize=15, device=0):
+    M = np.ascontiguousarray(M, np.float32)
+    H, W = M.shape[:2]
+    flow = np.empty((H, W, 2), np.float32)
+    check(load().ofc_box_solve(device, ptr(M), W, H, winsize, ptr(flow)))
+    return flow
+
+
+def flow_resize(flow, dw, dh, mul=1.0, device=0):
+    flow = np.ascontiguousarray(flow, np.float32)
+    sh, sw = flow.shape[:2]
+    out = np.empty((dh, dw, 2), np.float32)
+    check(load().ofc_flow_resize(device, ptr(flow), sw, sh, dw, dh, mul, ptr(out)))
+    return out
+
+
+def bench_polyexp(W, H, n_images, iters, rows_per_block=0, device=0):
+    ms = C.c_float()
+    check(load().ofc_bench_polyexp(device, W, H, n_images, iters, rows_per_block, C.byref(ms)))
+    return ms.value

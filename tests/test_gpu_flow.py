@@ -1,0 +1,145 @@
+"""GPU parity of the Farneback kernels against the CPU oracle, stage by stage and end to end, through
+the C ABI (libofc.so).  Tolerances: memory-bound kernels with FP contraction off are bit-exact; polyexp
+(FMA) and the box filter (exact f64 sums vs the reference's rounded running sums) agree to ~1e-6; the
+end-to-end bar is BASELINE.md section 5: ||d||2/||ref||2 <= 1e-4 per frame and max|d| <= 1e-3 px."""
+import numpy as np
+import pytest
+
+from opticalflowclustering_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    from opticalflowclustering_amd import stages
+    return stages
+
+
+def rel(a, b):
+    return np.linalg.norm((a - b).ravel().astype(np.float64)) / max(np.linalg.norm(b.ravel().astype(np.float64)), 1e-30)
+
+
+@pytest.mark.parametrize("W,H", [(256, 256), (480, 270), (322, 198), (1280, 720)])
+def test_level_image_bit_exact(st, W, H):
+    rng = np.random.default_rng(W + H)
+    gray = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    for k in range(O.pyramid_levels(W, H) + 1):
+        got, want = st.level_image(gray, k), O.level_image(gray, k)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (k, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("W,H", [(240, 135), (250, 37), (64, 16), (17, 200), (963, 541)])
+def test_polyexp(st, W, H):
+    rng = np.random.default_rng(W * H)
+    img = (rng.random((H, W)) * 255).astype(np.float32)
+    got, want = st.polyexp(img), O.polyexp(img)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    assert rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("W,H", [(96, 80), (480, 270), (257, 131)])
+def test_update_matrices_bit_exact(st, W, H):
+    a, b = synth.translated_pair(W, H, 2.3, -1.1)
+    R0, R1 = O.polyexp(O.level_image(a, 0)), O.polyexp(O.level_image(b, 0))
+    rng = np.random.default_rng(0)
+    flow = (rng.standard_normal((H, W, 2)) * 3).astype(np.float32)
+    flow[0, 0] = (-50, -50)          # out-of-range sample branch
+    flow[-1, -1] = (50, 50)
+    got, want = st.update_matrices(R0, R1, flow), O.update_matrices(R0, R1, flow)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("W,H", [(96, 80), (480, 270), (243, 77), (700, 33)])
+def test_box_solve(st, W, H):
+    rng = np.random.default_rng(W)
+    M = rng.random((H, W, 5)).astype(np.float32)
+    M[..., 0] += 1
+    M[..., 2] += 1
+    z5 = np.zeros((H, W, 5), np.float32)
+    want, _ = O.update_flow_blur(z5, z5, np.zeros((H, W, 2), np.float32), M, 15, False)
+    got = st.box_solve(M, 15)
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_box_solve_other_window(st):
+    rng = np.random.default_rng(5)
+    M = rng.random((60, 130, 5)).astype(np.float32) + np.float32([1, 0, 1, 0, 0])
+    z5 = np.zeros((60, 130, 5), np.float32)
+    for ws in (5, 9, 17):
+        want, _ = O.update_flow_blur(z5, z5, np.zeros((60, 130, 2), np.float32), M, ws, False)
+        assert np.abs(st.box_solve(M, ws) - want).max() <= 1e-5
+
+
+def test_flow_resize_bit_exact(st):
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((135, 240, 2)).astype(np.float32)
+    for (dw, dh) in [(480, 270), (427, 241), (240, 135)]:
+        want = O.resize_linear(f, dw, dh) * np.float32(2.0)
+        assert np.array_equal(st.flow_resize(f, dw, dh, 2.0), want)
+
+
+CASES = [("t1", 480, 270, lambda W, H: synth.translated_pair(W, H, 1.5, -0.75)),
+         ("t2", 480, 270, lambda W, H: synth.translated_pair(W, H, 4.0, 2.5)),
+         ("t3", 640, 360, lambda W, H: synth.translated_pair(W, H, 0.3, 0.2)),
+         ("nonrigid", 640, 360, lambda W, H: synth.nonrigid_pair(W, H)[:2]),
+         ("noise", 256, 256, lambda W, H: synth.noise_pair(W, H)),
+         ("odd", 322, 198, lambda W, H: synth.translated_pair(W, H, -2.2, 1.3))]
+
+
+@pytest.mark.parametrize("name,W,H,gen", CASES, ids=[c[0] for c in CASES])
+def test_flow_end_to_end(name, W, H, gen):
+    from opticalflowclustering_amd.flow import FlowEngine
+    a, b = gen(W, H)
+    want = O.farneback(a, b)
+    eng = FlowEngine(W, H)
+    got = eng.calc(a, b)
+    eng.close()
+    assert rel(got, want) <= 1e-4, rel(got, want)
+    assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
+
+
+def test_flow_1080p_known_translation_and_oracle():
+    from opticalflowclustering_amd.flow import FlowEngine
+    W, H = 1920, 1080
+    a, b = synth.translated_pair(W, H, 1.5, -0.75)
+    eng = FlowEngine(W, H)
+    got = eng.calc(a, b)
+    inner = got[40:-40, 40:-40]
+    assert abs(np.median(inner[..., 0]) - 1.5) < 0.02 and abs(np.median(inner[..., 1]) + 0.75) < 0.02
+    want = O.farneback(a, b)
+    assert rel(got, want) <= 1e-4 and np.abs(got - want).max() <= 1e-3
+    eng.close()
+
+
+def test_batched_device_path_equals_pairwise():
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.flow import FlowEngine
+    W, H, T = 480, 270, 5
+    p = synth.texture_params(3)
+    frames = np.stack([synth.frame(W, H, 0.8 * t, -0.4 * t, p) for t in range(T)])
+    eng = FlowEngine(W, H, max_batch=T - 1)
+    fd = _lib.DeviceBuffer(frames.nbytes).upload(frames)
+    od = _lib.DeviceBuffer((T - 1) * H * W * 8)
+    eng.calc_frames_dev(fd.ptr, T, od.ptr)
+    flows = od.download((T - 1, H, W, 2), np.float32)
+    for t in range(T - 1):
+        assert np.array_equal(flows[t], eng.calc(frames[t], frames[t + 1]))
+    # streaming form
+    assert eng.push(frames[0]) is None
+    assert np.array_equal(eng.push(frames[1]), flows[0])
+    assert np.array_equal(eng.push(frames[2]), flows[1])
+    eng.close()
+
+
+def test_bad_arguments_raise():
+    from opticalflowclustering_amd._lib import FbParams, OfcError
+    from opticalflowclustering_amd.flow import FlowEngine
+    with pytest.raises(OfcError):
+        FlowEngine(64, 64, FbParams(flags=256))          # OPTFLOW_FARNEBACK_GAUSSIAN not implemented
+    eng = FlowEngine(64, 64)
+    with pytest.raises(ValueError):
+        eng.calc(np.zeros((32, 32), np.uint8), np.zeros((32, 32), np.uint8))
+    eng.close()
