@@ -1,0 +1,305 @@
+// lloyd_api.cpp -- C ABI of libofc.so, part 2: Lloyd k-means drivers (streaming shape).
+// Control flow = sklearn's _kmeans_single_lloyd (_kmeans.py:624-752) around the kernels of
+// lloyd_kernels.hip; see include/ofc.h for the reference call sites.
+#include "lloyd_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ofc {
+
+static double np_sum_small(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC_F32 ? 4 : 8); }
+
+struct LloydScratch {
+    DevBuf state, partial, tot, excl, far, labels;
+    LloydStatus *status = nullptr;       // pinned, device-visible
+    LloydStatus *status_dev = nullptr;
+    hipStream_t stream = nullptr;
+    ~LloydScratch()
+    {
+        if (status) (void)hipHostFree(status);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// empty-cluster relocation (_k_means_common.pyx:167-211) on the all-reduced totals `tot`.
+// Returns with `tot` patched on the device (or untouched when the farthest distance is 0).
+static int relocate_empty(LloydScratch &sc, const void *X, int dtype, int64_t N, int d, int k, int kmax,
+                          int nblocks, const uint8_t *labels, const double *mean_h)
+{
+    hipStream_t s = sc.stream;
+    const int NV = kmax * d + kmax + 1;
+    std::vector<double> tot(NV);
+    OFC_HIP(hipMemcpyAsync(tot.data(), sc.tot.p, sizeof(double) * NV, hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    double *w = tot.data() + kmax * d;
+    LloydState *st = sc.state.as<LloydState>();
+    const double *c_old = st->centers;          // device address of the member array
+    std::vector<int64_t> excl;
+    std::vector<double> blk(2 * nblocks);
+    bool first = true;
+    for (int j = 0; j < k; j++) {
+        if (w[j] != 0.0) continue;
+        if (!excl.empty())
+            OFC_HIP(hipMemcpyAsync(sc.excl.p, excl.data(), sizeof(int64_t) * excl.size(), hipMemcpyHostToDevice, s));
+        OFC_TRY(launch_lloyd_farthest(X, dtype, N, d, st, c_old, labels, sc.excl.as<int64_t>(), (int)excl.size(),
+                                      sc.far.as<double>(), nblocks, s));
+        OFC_HIP(hipMemcpyAsync(blk.data(), sc.far.p, sizeof(double) * 2 * nblocks, hipMemcpyDeviceToHost, s));
+        OFC_HIP(hipStreamSynchronize(s));
+        double best = -1;
+        int64_t bi = -1;
+        for (int b = 0; b < nblocks; b++) {
+            const double v = blk[2 * b];
+            const int64_t i = (int64_t)blk[2 * b + 1];
+            if (i < 0) continue;
+            if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+        }
+        // global winner across ranks: max distance, ties -> lowest rank (= lowest global index)
+        double rec[LLOYD_DMAX + 3];   // [dist | rank-or-inf | x_c[d] | old label]
+        int owner = 1;
+        if (dist_active()) {
+            double *dv = sc.far.as<double>();
+            double g = best;
+            OFC_HIP(hipMemcpyAsync(dv, &g, sizeof(double), hipMemcpyHostToDevice, s));
+            OFC_TRY(dist_allreduce_f64(dv, 1, DIST_MAX, s));
+            OFC_HIP(hipMemcpyAsync(&g, dv, sizeof(double), hipMemcpyDeviceToHost, s));
+            OFC_HIP(hipStreamSynchronize(s));
+            double r = (bi >= 0 && best == g) ? (double)dist_rank() : 1e300;
+            OFC_HIP(hipMemcpyAsync(dv, &r, sizeof(double), hipMemcpyHostToDevice, s));
+            OFC_TRY(dist_allreduce_f64(dv, 1, DIST_MIN, s));
+            OFC_HIP(hipMemcpyAsync(&r, dv, sizeof(double), hipMemcpyDeviceToHost, s));
+            OFC_HIP(hipStreamSynchronize(s));
+            owner = ((int)r == dist_rank()) && bi >= 0 && best == g;
+            best = g;
+        }
+        if (first && !(best > 0)) return OFC_OK;   // np.max(distances) == 0: relocating is pointless
+        first = false;
+        memset(rec, 0, sizeof(rec));
+        if (owner) {
+            unsigned char raw[LLOYD_DMAX * 8];
+            uint8_t lab;
+            OFC_HIP(hipMemcpyAsync(raw, (const char *)X + (size_t)bi * d * dtype_size(dtype), d * dtype_size(dtype),
+                                   hipMemcpyDeviceToHost, s));
+            OFC_HIP(hipMemcpyAsync(&lab, labels + bi, 1, hipMemcpyDeviceToHost, s));
+            OFC_HIP(hipStreamSynchronize(s));
+            for (int f = 0; f < d; f++) {
+                double v = dtype == OFC_U8 ? (double)raw[f]
+                         : dtype == OFC_F32 ? (double)((float *)raw)[f] : ((double *)raw)[f];
+                rec[f] = v - mean_h[f];
+            }
+            rec[d] = (double)lab;
+            excl.push_back(bi);
+        }
+        if (dist_active()) {
+            double *dv = sc.far.as<double>();
+            OFC_HIP(hipMemcpyAsync(dv, rec, sizeof(double) * (d + 1), hipMemcpyHostToDevice, s));
+            OFC_TRY(dist_allreduce_f64(dv, d + 1, DIST_SUM, s));
+            OFC_HIP(hipMemcpyAsync(rec, dv, sizeof(double) * (d + 1), hipMemcpyDeviceToHost, s));
+            OFC_HIP(hipStreamSynchronize(s));
+        }
+        const int old = (int)rec[d];
+        for (int f = 0; f < d; f++) {
+            tot[old * d + f] -= rec[f];
+            tot[j * d + f] = rec[f];
+        }
+        w[j] = 1.0;
+        w[old] -= 1.0;
+    }
+    OFC_HIP(hipMemcpyAsync(sc.tot.p, tot.data(), sizeof(double) * NV, hipMemcpyHostToDevice, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    return OFC_OK;
+}
+
+static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d, int k, const double *init,
+                         int max_iter, double tol_rel, double *centers, uint8_t *labels_dev,
+                         double *inertia, int *n_iter)
+{
+    OFC_REQUIRE(X && init && centers, "null pointer");
+    OFC_REQUIRE(dtype >= OFC_U8 && dtype <= OFC_F64, "bad dtype %d", dtype);
+    OFC_REQUIRE(d >= 1 && k >= 1 && max_iter >= 1 && N >= 0, "bad shape");
+    if (d > LLOYD_DMAX || k > LLOYD_KMAX) {
+        set_error("k=%d, d=%d outside the kernels' range (k <= %d, d <= %d)", k, d, LLOYD_KMAX, LLOYD_DMAX);
+        return OFC_EUNSUPPORTED;
+    }
+    OFC_TRY(ensure_device(device));
+    const int kmax = lloyd_kmax(k);
+    const int NV = kmax * d + kmax + 1;
+    LloydScratch sc;
+    OFC_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+    hipStream_t s = sc.stream;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+    OFC_TRY(sc.state.alloc(sizeof(LloydState)));
+    OFC_TRY(sc.partial.alloc(sizeof(double) * (size_t)nblocks * NV));
+    OFC_TRY(sc.tot.alloc(sizeof(double) * (NV + 8)));
+    OFC_TRY(sc.excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
+    OFC_TRY(sc.far.alloc(sizeof(double) * std::max(2 * nblocks, 16)));
+    OFC_HIP(hipHostMalloc((void **)&sc.status, sizeof(LloydStatus), hipHostMallocMapped));
+    OFC_HIP(hipHostGetDevicePointer((void **)&sc.status_dev, sc.status, 0));
+    if (!labels_dev) {
+        OFC_TRY(sc.labels.alloc((size_t)std::max<int64_t>(N, 1)));
+        labels_dev = sc.labels.as<uint8_t>();
+    }
+    LloydState *st = sc.state.as<LloydState>();
+    OFC_HIP(hipMemsetAsync(st, 0, sizeof(LloydState), s));
+    double *tot = sc.tot.as<double>();
+
+    // ---- column mean (X.mean(axis=0), _kmeans.py:1478-1484) and tol (_tolerance, :279-287) ----
+    double hbuf[LLOYD_DMAX + 1], mean_h[LLOYD_DMAX], var_h[LLOYD_DMAX];
+    OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 0, sc.partial.as<double>(), nblocks, s));
+    OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
+    double nloc = (double)N;
+    OFC_HIP(hipMemcpyAsync(tot + d, &nloc, sizeof(double), hipMemcpyHostToDevice, s));
+    OFC_TRY(dist_allreduce_f64(tot, d + 1, DIST_SUM, s));
+    OFC_HIP(hipMemcpyAsync(hbuf, tot, sizeof(double) * (d + 1), hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    const double Ng = hbuf[d];
+    if (Ng < (double)k) {
+        set_error("n_samples=%.0f should be >= n_clusters=%d.", Ng, k);
+        return OFC_EINVAL;
+    }
+    for (int f = 0; f < d; f++) mean_h[f] = hbuf[f] / Ng;
+    OFC_HIP(hipMemcpyAsync(st->mean, mean_h, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 1, sc.partial.as<double>(), nblocks, s));
+    OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
+    OFC_TRY(dist_allreduce_f64(tot, d, DIST_SUM, s));
+    OFC_HIP(hipMemcpyAsync(var_h, tot, sizeof(double) * d, hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    for (int f = 0; f < d; f++) var_h[f] /= Ng;
+    const double tol = (tol_rel == 0) ? 0 : np_sum_small(var_h, d) / (double)d * tol_rel;
+
+    // ---- centred init ----
+    double c0[LLOYD_KMAX * LLOYD_DMAX];
+    for (int j = 0; j < k * d; j++) c0[j] = init[j] - mean_h[j % d];
+    OFC_HIP(hipMemcpyAsync(st->centers, c0, sizeof(double) * k * d, hipMemcpyHostToDevice, s));
+    OFC_TRY(launch_lloyd_set_centers(st, k, d, s));
+    OFC_HIP(hipMemsetAsync(labels_dev, 0xFF, (size_t)N, s));
+
+    // ---- Lloyd iterations ----
+    bool strict = false;
+    int it = 0;
+    for (it = 0; it < max_iter; it++) {
+        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, true, s));
+        OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s));
+        OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
+        OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, sc.status_dev, s));
+        OFC_HIP(hipStreamSynchronize(s));
+        if (sc.status->n_empty > 0) {
+            OFC_TRY(relocate_empty(sc, X, dtype, N, d, k, kmax, nblocks, labels_dev, mean_h));
+            OFC_TRY(launch_lloyd_update(st, tot, k, d, 1, sc.status_dev, s));
+            OFC_HIP(hipStreamSynchronize(s));
+        }
+        if (sc.status->n_changed == 0.0) { strict = true; break; }
+        if (sc.status->shift_tot <= tol) break;
+    }
+    if (it == max_iter) it = max_iter - 1;
+    if (!strict)
+        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, false, s));
+    // ---- inertia, un-centred centres ----
+    OFC_TRY(launch_lloyd_inertia(X, dtype, N, d, st, labels_dev, sc.partial.as<double>(), nblocks, s));
+    OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, 1, tot, s));
+    OFC_TRY(dist_allreduce_f64(tot, 1, DIST_SUM, s));
+    double in = 0, cfin[LLOYD_KMAX * LLOYD_DMAX];
+    OFC_HIP(hipMemcpyAsync(&in, tot, sizeof(double), hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipMemcpyAsync(cfin, st->centers, sizeof(double) * k * d, hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    for (int j = 0; j < k * d; j++) centers[j] = cfin[j] + mean_h[j % d];
+    if (inertia) *inertia = in;
+    if (n_iter) *n_iter = it + 1;
+    return OFC_OK;
+}
+
+static int lloyd_predict_dev(int device, const void *X, int dtype, int64_t N, int d, int k,
+                             const double *centers, uint8_t *labels_dev)
+{
+    OFC_TRY(ensure_device(device));
+    if (d > LLOYD_DMAX || k > LLOYD_KMAX || d < 1 || k < 1) {
+        set_error("k=%d, d=%d outside the kernels' range (k <= %d, d <= %d)", k, d, LLOYD_KMAX, LLOYD_DMAX);
+        return OFC_EUNSUPPORTED;
+    }
+    DevBuf state;
+    OFC_TRY(state.alloc(sizeof(LloydState)));
+    LloydState *st = state.as<LloydState>();
+    OFC_HIP(hipMemset(st, 0, sizeof(LloydState)));
+    OFC_HIP(hipMemcpy(st->centers, centers, sizeof(double) * k * d, hipMemcpyHostToDevice));
+    OFC_TRY(launch_lloyd_set_centers(st, k, d, nullptr));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+    OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, false, nullptr));
+    OFC_HIP(hipStreamSynchronize(nullptr));
+    return OFC_OK;
+}
+
+static void widen_labels(const uint8_t *src, int64_t N, int32_t *dst)
+{
+    for (int64_t i = 0; i < N; i++) dst[i] = src[i];
+}
+
+}  // namespace ofc
+
+using namespace ofc;
+
+extern "C" {
+
+int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *init,
+                       int max_iter, double tol_rel, double *centers, uint8_t *labels_dev, double *inertia,
+                       int *n_iter)
+{
+    return lloyd_fit_dev(device, X_dev, dtype, N, d, k, init, max_iter, tol_rel, centers, labels_dev, inertia, n_iter);
+}
+
+int ofc_kmeans_fit(int device, const void *X, int dtype, int64_t N, int d, int k, const double *init,
+                   int max_iter, double tol_rel, double *centers, int32_t *labels, double *inertia, int *n_iter)
+{
+    OFC_REQUIRE(X && init && centers, "null pointer");
+    OFC_REQUIRE(dtype >= OFC_U8 && dtype <= OFC_F64 && d >= 1 && N >= 0, "bad arguments");
+    OFC_REQUIRE(N >= k, "n_samples=%lld should be >= n_clusters=%d.", (long long)N, k);
+    OFC_TRY(ensure_device(device));
+    DevBuf dX, dL;
+    const size_t bytes = (size_t)N * d * dtype_size(dtype);
+    OFC_TRY(dX.alloc(std::max<size_t>(bytes, 16)));
+    OFC_TRY(dL.alloc((size_t)std::max<int64_t>(N, 1)));
+    OFC_HIP(hipMemcpy(dX.p, X, bytes, hipMemcpyHostToDevice));
+    OFC_TRY(lloyd_fit_dev(device, dX.p, dtype, N, d, k, init, max_iter, tol_rel, centers, dL.as<uint8_t>(), inertia, n_iter));
+    if (labels) {
+        std::vector<uint8_t> l8((size_t)N);
+        OFC_HIP(hipMemcpy(l8.data(), dL.p, (size_t)N, hipMemcpyDeviceToHost));
+        widen_labels(l8.data(), N, labels);
+    }
+    return OFC_OK;
+}
+
+int ofc_kmeans_predict(int device, const void *X, int dtype, int64_t N, int d, int k, const double *centers,
+                       int32_t *labels)
+{
+    OFC_REQUIRE(X && centers && labels, "null pointer");
+    OFC_REQUIRE(dtype >= OFC_U8 && dtype <= OFC_F64 && d >= 1 && N >= 0 && k >= 1, "bad arguments");
+    OFC_TRY(ensure_device(device));
+    DevBuf dX, dL;
+    const size_t bytes = (size_t)N * d * dtype_size(dtype);
+    OFC_TRY(dX.alloc(std::max<size_t>(bytes, 16)));
+    OFC_TRY(dL.alloc((size_t)std::max<int64_t>(N, 1)));
+    OFC_HIP(hipMemcpy(dX.p, X, bytes, hipMemcpyHostToDevice));
+    OFC_TRY(lloyd_predict_dev(device, dX.p, dtype, N, d, k, centers, dL.as<uint8_t>()));
+    std::vector<uint8_t> l8((size_t)N);
+    OFC_HIP(hipMemcpy(l8.data(), dL.p, (size_t)N, hipMemcpyDeviceToHost));
+    widen_labels(l8.data(), N, labels);
+    return OFC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// lloyd_common.h -- device-side state and launcher prototypes of the Lloyd kernels.
+#pragma once
+#include "ofc_common.h"
+
+namespace ofc {
+
+constexpr int LLOYD_KMAX = 16;   // streaming / batched kernels keep per-lane partials in registers
+constexpr int LLOYD_DMAX = 4;
+
+// lives in device memory; centres are stored CENTRED (x - column mean), as sklearn iterates
+struct LloydState {
+    double mean[LLOYD_DMAX];
+    double centers[LLOYD_KMAX * LLOYD_DMAX];      // current (old) centres, row-major k x d
+    double centers_new[LLOYD_KMAX * LLOYD_DMAX];
+    double cn[LLOYD_KMAX];                        // |c_j|^2 (FMA chain)
+};
+
+// written by k_lloyd_update into pinned host memory once per iteration
+struct LloydStatus {
+    double n_changed;
+    double shift_tot;
+    int n_empty;
+    int pad;
+    double counts[LLOYD_KMAX];
+};
+
+int lloyd_kmax(int k);
+int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const double *mean, int pass,
+                          double *partial, int nblocks, hipStream_t s);
+int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s);
+int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
+                        uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s);
+int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc,
+                        LloydStatus *status, hipStream_t s);
+int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s);
+int launch_lloyd_inertia(const void *X, int dtype, int64_t N, int d, const LloydState *st,
+                         const uint8_t *labels, double *partial, int nblocks, hipStream_t s);
+int launch_lloyd_farthest(const void *X, int dtype, int64_t N, int d, const LloydState *st,
+                          const double *c_old, const uint8_t *labels, const int64_t *excl, int n_excl,
+                          double *out, int nblocks, hipStream_t s);
+
+// distributed plumbing (dist.cpp): no-ops when no communicator is set up
+bool dist_active();
+int dist_rank();
+int dist_world();
+enum { DIST_SUM = 0, DIST_MAX = 1, DIST_MIN = 2 };
+int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s);
+
+}  // namespace ofc

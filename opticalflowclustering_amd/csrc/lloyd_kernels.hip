@@ -1,0 +1,547 @@
+// lloyd_kernels.hip -- hand-written gfx950 kernels for Lloyd's k-means in the two shapes the path needs
+// (SURVEY.md 2.2 K11):
+//   (B) streaming: one huge problem resident in HBM ((u,v) of a whole clip, f32 d=2; also u8/f64, d<=8),
+//       10 B/point/iteration algorithmic (4d read + 1 label read + 1 label write);
+//   (A) batched-small: hundreds of independent problems (grid cells, u8 RGBA), one work-group per
+//       problem with the points resident in LDS for all iterations (lloyd_batched.hip).
+// Arithmetic = the oracle's (oracle/lloyd_ref.c == sklearn): f64 everywhere, data centred by the column
+// mean, D_j = |c_j|^2 - 2 x.c_j with the dot product as a sequential FMA chain, first strict minimum wins.
+// Reductions are deterministic: per-lane partials -> wave shuffle tree -> LDS -> one record per
+// work-group -> fixed-order finishing kernel.  No atomics anywhere.
+#include "lloyd_common.h"
+
+namespace ofc {
+
+// ------------------------------------------------------------------------------------------------
+// loaders: 4 consecutive points per lane as doubles
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void load4(const uint8_t *X, int64_t i, double (&x)[4][D])
+{
+    if constexpr (D == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(X + i * 4);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int f = 0; f < 4; f++) x[p][f] = (double)((w[p] >> (8 * f)) & 0xffu);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int f = 0; f < D; f++) x[p][f] = (double)X[(i + p) * D + f];
+    }
+}
+template <int D>
+__device__ __forceinline__ void load4(const float *X, int64_t i, double (&x)[4][D])
+{
+    if constexpr (D == 2) {
+        const float4 a = *reinterpret_cast<const float4 *>(X + i * 2);
+        const float4 b = *reinterpret_cast<const float4 *>(X + i * 2 + 4);
+        x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
+        x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
+    } else if constexpr (D == 4) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float4 a = *reinterpret_cast<const float4 *>(X + (i + p) * 4);
+            x[p][0] = a.x; x[p][1] = a.y; x[p][2] = a.z; x[p][3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int f = 0; f < D; f++) x[p][f] = (double)X[(i + p) * D + f];
+    }
+}
+template <int D>
+__device__ __forceinline__ void load4(const double *X, int64_t i, double (&x)[4][D])
+{
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int f = 0; f < D; f++) x[p][f] = X[(i + p) * D + f];
+}
+template <int D, class T>
+__device__ __forceinline__ void load1(const T *X, int64_t i, double (&x)[D])
+{
+#pragma unroll
+    for (int f = 0; f < D; f++) x[f] = (double)X[i * D + f];
+}
+
+// deterministic work-group sum of NV doubles per thread -> out[NV] (thread 0..NV-1 write)
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *lds /*[4][NV]*/, double *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        double a = v[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) lds[wave * NV + i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int i = threadIdx.x;
+        out[i] = ((lds[i] + lds[NV + i]) + lds[2 * NV + i]) + lds[3 * NV + i];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// column statistics: pass 0 = sum x, pass 1 = sum (x-mean)^2   -> partial[block][D]
+// ------------------------------------------------------------------------------------------------
+template <int D, class T>
+__global__ __launch_bounds__(256) void k_colstats(const T *__restrict__ X, int64_t N,
+                                                  const double *__restrict__ mean, int pass,
+                                                  double *__restrict__ partial)
+{
+    __shared__ double lds[4 * D];
+    double acc[D], m[D];
+#pragma unroll
+    for (int f = 0; f < D; f++) { acc[f] = 0; m[f] = pass ? mean[f] : 0.0; }
+    const int64_t n4 = N / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        double x[4][D];
+        load4<D>(X, q * 4, x);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int f = 0; f < D; f++) {
+                const double t = x[p][f] - m[f];
+                acc[f] += pass ? t * t : t;
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(N - n4 * 4)) {
+        double x[D];
+        load1<D>(X, n4 * 4 + threadIdx.x, x);
+#pragma unroll
+        for (int f = 0; f < D; f++) {
+            const double t = x[f] - m[f];
+            acc[f] += pass ? t * t : t;
+        }
+    }
+    block_reduce_store<D>(acc, lds, partial + (size_t)blockIdx.x * D);
+}
+
+// fixed-order sum of per-block records: out[i] = sum_b partial[b][i]
+__global__ __launch_bounds__(256) void k_reduce_records(const double *__restrict__ partial, int nblocks,
+                                                        int nv, double *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i >= nv) return;
+    double a = 0;
+    for (int b = 0; b < nblocks; b++) a += partial[(size_t)b * nv + i];
+    out[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// E-step (+ M-step accumulation).  Record per work-group: [k*d sums of (x-mean)][k counts][n_changed]
+// (laid out with stride KMAX: sums[j*D+f], counts at KMAX*D + j, changed at KMAX*D + KMAX).
+// ------------------------------------------------------------------------------------------------
+template <int D, int KMAX>
+__device__ __forceinline__ int assign_point(const double (&x)[D], const double *c /*[KMAX*D] regs*/,
+                                            const double *cn, int k)
+{
+    double best = 0;
+    int label = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+        if (j < k) {
+            double acc = x[0] * c[j * D];
+#pragma unroll
+            for (int f = 1; f < D; f++) acc = fma(x[f], c[j * D + f], acc);
+            const double dj = cn[j] - 2.0 * acc;
+            if (j == 0 || dj < best) { best = dj; label = j; }
+        }
+    }
+    return label;
+}
+
+template <int D, int KMAX, class T, bool ACCUM>
+__global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k,
+                                                      const LloydState *__restrict__ st,
+                                                      uint8_t *__restrict__ labels,
+                                                      double *__restrict__ partial)
+{
+    constexpr int NV = KMAX * D + KMAX + 1;
+    __shared__ double lds[ACCUM ? 4 * NV : 1];
+    double c[KMAX * D], cn[KMAX], m[D];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+        cn[j] = (j < k) ? st->cn[j] : 0.0;
+#pragma unroll
+        for (int f = 0; f < D; f++) c[j * D + f] = (j < k) ? st->centers[j * D + f] : 0.0;
+    }
+#pragma unroll
+    for (int f = 0; f < D; f++) m[f] = st->mean[f];
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) acc[i] = 0;
+
+    const int64_t n4 = N / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        double x[4][D];
+        load4<D>(X, q * 4, x);
+        const uchar4 lo = reinterpret_cast<const uchar4 *>(labels)[q];
+        const int old[4] = {lo.x, lo.y, lo.z, lo.w};
+        int nl[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+#pragma unroll
+            for (int f = 0; f < D; f++) x[p][f] -= m[f];
+            nl[p] = assign_point<D, KMAX>(x[p], c, cn, k);
+            if (ACCUM) {
+#pragma unroll
+                for (int j = 0; j < KMAX; j++) {
+                    const bool hit = (nl[p] == j);
+                    acc[KMAX * D + j] += hit ? 1.0 : 0.0;
+#pragma unroll
+                    for (int f = 0; f < D; f++) acc[j * D + f] += hit ? x[p][f] : 0.0;
+                }
+                acc[NV - 1] += (nl[p] != old[p]) ? 1.0 : 0.0;
+            }
+        }
+        reinterpret_cast<uchar4 *>(labels)[q] = make_uchar4(nl[0], nl[1], nl[2], nl[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(N - n4 * 4)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        double x[D];
+        load1<D>(X, i, x);
+#pragma unroll
+        for (int f = 0; f < D; f++) x[f] -= m[f];
+        const int l = assign_point<D, KMAX>(x, c, cn, k);
+        if (ACCUM) {
+#pragma unroll
+            for (int j = 0; j < KMAX; j++) {
+                const bool hit = (l == j);
+                acc[KMAX * D + j] += hit ? 1.0 : 0.0;
+#pragma unroll
+                for (int f = 0; f < D; f++) acc[j * D + f] += hit ? x[f] : 0.0;
+            }
+            acc[NV - 1] += (l != labels[i]) ? 1.0 : 0.0;
+        }
+        labels[i] = (uint8_t)l;
+    }
+    if (ACCUM) block_reduce_store<NV>(acc, lds, partial + (size_t)blockIdx.x * NV);
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-step finish on one lane: (optional relocation is done by the host before this), average, shift,
+// convergence inputs.  tot: [KMAX*D sums][KMAX counts][changed] (already all-reduced if distributed).
+// Follows _average_centers / _center_shift (_k_means_common.pyx:274-311) incl. the in-place quirk for
+// still-empty clusters.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, int k, int d, int kmax,
+                               int after_reloc, LloydStatus *status /* pinned host */)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double *cnew = st->centers_new;
+    const double *w = tot + kmax * d;
+    int amax = 0, n_empty = 0;
+    for (int j = 0; j < k; j++) {
+        if (w[j] > w[amax]) amax = j;
+        n_empty += (w[j] == 0.0);
+    }
+    if (n_empty > 0 && !after_reloc) {
+        // _relocate_empty_clusters_dense needs a pass over the data: hand back to the host, which
+        // patches `tot` and calls again with after_reloc = 1.  Nothing is modified here.
+        status->n_empty = n_empty;
+        status->n_changed = tot[kmax * d + kmax];
+        status->shift_tot = -1;
+        for (int j = 0; j < k; j++) status->counts[j] = w[j];
+        return;
+    }
+    for (int j = 0; j < k; j++)
+        for (int f = 0; f < d; f++) cnew[j * d + f] = tot[j * d + f];
+    for (int j = 0; j < k; j++) {
+        if (w[j] > 0) {
+            const double alpha = 1.0 / w[j];
+            for (int f = 0; f < d; f++) cnew[j * d + f] *= alpha;
+        } else {
+            for (int f = 0; f < d; f++) cnew[j * d + f] = cnew[amax * d + f];
+        }
+    }
+    // shift (4-way grouped squared distance, then sqrt, squared again and summed numpy-style)
+    double sh2[256];
+    for (int j = 0; j < k; j++) {
+        const double *a = cnew + j * d, *b = st->centers + j * d;
+        double r = 0;
+        int f = 0;
+        for (; f + 4 <= d; f += 4)
+            r += ((a[f] - b[f]) * (a[f] - b[f]) + (a[f + 1] - b[f + 1]) * (a[f + 1] - b[f + 1]) +
+                  (a[f + 2] - b[f + 2]) * (a[f + 2] - b[f + 2]) + (a[f + 3] - b[f + 3]) * (a[f + 3] - b[f + 3]));
+        for (; f < d; f++) r += (a[f] - b[f]) * (a[f] - b[f]);
+        const double s = sqrt(r);
+        sh2[j] = s * s;
+    }
+    double tot_shift;
+    if (k < 8) {
+        tot_shift = 0;
+        for (int j = 0; j < k; j++) tot_shift += sh2[j];
+    } else {   // numpy pairwise sum, n <= 128 block
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = sh2[i];
+        for (i = 8; i < k - (k % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += sh2[i + j];
+        tot_shift = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < k; i++) tot_shift += sh2[i];
+    }
+    // swap: centers <- centers_new, new |c|^2
+    for (int j = 0; j < k; j++) {
+        double acc = cnew[j * d] * cnew[j * d];
+        for (int f = 1; f < d; f++) acc = fma(cnew[j * d + f], cnew[j * d + f], acc);
+        st->cn[j] = acc;
+        for (int f = 0; f < d; f++) st->centers[j * d + f] = cnew[j * d + f];
+    }
+    status->n_changed = tot[kmax * d + kmax];
+    status->shift_tot = tot_shift;
+    status->n_empty = 0;
+    for (int j = 0; j < k; j++) status->counts[j] = w[j];
+}
+
+// sets centres (centred) + |c|^2 from host-provided values
+__global__ void k_lloyd_set_centers(LloydState *st, int k, int d)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int j = 0; j < k; j++) {
+        double acc = st->centers[j * d] * st->centers[j * d];
+        for (int f = 1; f < d; f++) acc = fma(st->centers[j * d + f], st->centers[j * d + f], acc);
+        st->cn[j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inertia = sum ||x - c_label||^2 (centred), _inertia_dense grouping; partial[block][1]
+// and farthest-point search for empty-cluster relocation: partial[block] = {max dist, index}
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double sq_euclid_grouped(const double (&a)[D], const double *b)
+{
+#pragma clang fp contract(off)
+    double r = 0;
+    int f = 0;
+#pragma unroll
+    for (; f + 4 <= D; f += 4)
+        r += ((a[f] - b[f]) * (a[f] - b[f]) + (a[f + 1] - b[f + 1]) * (a[f + 1] - b[f + 1]) +
+              (a[f + 2] - b[f + 2]) * (a[f + 2] - b[f + 2]) + (a[f + 3] - b[f + 3]) * (a[f + 3] - b[f + 3]));
+#pragma unroll
+    for (; f < D; f++) r += (a[f] - b[f]) * (a[f] - b[f]);
+    return r;
+}
+
+template <int D, class T>
+__global__ __launch_bounds__(256) void k_lloyd_inertia(const T *__restrict__ X, int64_t N,
+                                                       const LloydState *__restrict__ st,
+                                                       const uint8_t *__restrict__ labels,
+                                                       double *__restrict__ partial)
+{
+    __shared__ double lds[4];
+    double acc[1] = {0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        double x[D];
+        load1<D>(X, i, x);
+#pragma unroll
+        for (int f = 0; f < D; f++) x[f] -= st->mean[f];
+        acc[0] += sq_euclid_grouped<D>(x, st->centers + (int)labels[i] * D);
+    }
+    block_reduce_store<1>(acc, lds, partial + blockIdx.x);
+}
+
+// distance of every sample to its (old) assigned centre; work-group argmax, ties -> lowest index;
+// samples listed in excl[0..n_excl) are skipped.  out[block] = {dist, (double)index}
+template <int D, class T>
+__global__ __launch_bounds__(256) void k_lloyd_farthest(const T *__restrict__ X, int64_t N,
+                                                        const LloydState *__restrict__ st,
+                                                        const double *__restrict__ c_old,
+                                                        const uint8_t *__restrict__ labels,
+                                                        const int64_t *__restrict__ excl, int n_excl,
+                                                        double *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ double sv[256];
+    __shared__ int64_t si[256];
+    double best = -1;
+    int64_t bi = -1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        bool skip = false;
+        for (int e = 0; e < n_excl; e++) skip |= (excl[e] == i);
+        if (skip) continue;
+        double x[D];
+        load1<D>(X, i, x);
+        const double *c = c_old + (int)labels[i] * D;
+        double s = 0;
+#pragma unroll
+        for (int f = 0; f < D; f++) {
+            const double t = (x[f] - st->mean[f]) - c[f];
+            s += t * t;
+        }
+        if (s > best) { best = s; bi = i; }   // i increases per thread: first max kept
+    }
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = sv[threadIdx.x + off];
+            const int64_t oi = si[threadIdx.x + off];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi >= 0 && (si[threadIdx.x] < 0 || oi < si[threadIdx.x]))) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = sv[0];
+        out[2 * blockIdx.x + 1] = (double)si[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch over (dtype, D, KMAX)
+// ------------------------------------------------------------------------------------------------
+int lloyd_kmax(int k) { return k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : 0)); }
+
+template <int D, int KMAX, class T>
+static void launch_assign_t(const void *X, int64_t N, int k, const LloydState *st, uint8_t *labels,
+                            double *partial, int nblocks, bool accum, hipStream_t s)
+{
+    if (accum)
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, true>), dim3(nblocks), dim3(256), 0, s,
+                           (const T *)X, N, k, st, labels, partial);
+    else
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, false>), dim3(nblocks), dim3(256), 0, s,
+                           (const T *)X, N, k, st, labels, partial);
+}
+
+template <int D, int KMAX>
+static int launch_assign_d(const void *X, int dtype, int64_t N, int k, const LloydState *st,
+                           uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s)
+{
+    switch (dtype) {
+    case OFC_U8: launch_assign_t<D, KMAX, uint8_t>(X, N, k, st, labels, partial, nblocks, accum, s); break;
+    case OFC_F32: launch_assign_t<D, KMAX, float>(X, N, k, st, labels, partial, nblocks, accum, s); break;
+    case OFC_F64: launch_assign_t<D, KMAX, double>(X, N, k, st, labels, partial, nblocks, accum, s); break;
+    default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+#define OFC_D_SWITCH(d, ...)                                     \
+    switch (d) {                                                 \
+    case 1: { constexpr int DD = 1; __VA_ARGS__; } break;        \
+    case 2: { constexpr int DD = 2; __VA_ARGS__; } break;        \
+    case 3: { constexpr int DD = 3; __VA_ARGS__; } break;        \
+    case 4: { constexpr int DD = 4; __VA_ARGS__; } break;        \
+    default: set_error("d=%d unsupported (1..4)", d); return OFC_EUNSUPPORTED; \
+    }
+
+int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
+                        uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s)
+{
+    const int kmax = lloyd_kmax(k);
+    if (!kmax) { set_error("k=%d unsupported by the streaming kernel (1..16)", k); return OFC_EUNSUPPORTED; }
+    int rc = OFC_OK;
+    OFC_D_SWITCH(d, {
+        if (kmax == 4) rc = launch_assign_d<DD, 4>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
+        else if (kmax == 8) rc = launch_assign_d<DD, 8>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
+        else rc = launch_assign_d<DD, 16>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
+    })
+    return rc;
+}
+
+template <int D>
+static int launch_colstats_d(const void *X, int dtype, int64_t N, const double *mean, int pass,
+                             double *partial, int nblocks, hipStream_t s)
+{
+    switch (dtype) {
+    case OFC_U8: hipLaunchKernelGGL((k_colstats<D, uint8_t>), dim3(nblocks), dim3(256), 0, s, (const uint8_t *)X, N, mean, pass, partial); break;
+    case OFC_F32: hipLaunchKernelGGL((k_colstats<D, float>), dim3(nblocks), dim3(256), 0, s, (const float *)X, N, mean, pass, partial); break;
+    case OFC_F64: hipLaunchKernelGGL((k_colstats<D, double>), dim3(nblocks), dim3(256), 0, s, (const double *)X, N, mean, pass, partial); break;
+    default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const double *mean, int pass,
+                          double *partial, int nblocks, hipStream_t s)
+{
+    int rc = OFC_OK;
+    OFC_D_SWITCH(d, { rc = launch_colstats_d<DD>(X, dtype, N, mean, pass, partial, nblocks, s); })
+    return rc;
+}
+
+int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s)
+{
+    if (nv > 256) { set_error("record too long"); return OFC_EINVAL; }
+    hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(256), 0, s, partial, nblocks, nv, out);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc,
+                        LloydStatus *status, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lloyd_update, dim3(1), dim3(64), 0, s, st, tot, k, d, lloyd_kmax(k), after_reloc, status);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lloyd_set_centers, dim3(1), dim3(64), 0, s, st, k, d);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+template <int D>
+static int launch_inertia_d(const void *X, int dtype, int64_t N, const LloydState *st,
+                            const uint8_t *labels, double *partial, int nblocks, hipStream_t s)
+{
+    switch (dtype) {
+    case OFC_U8: hipLaunchKernelGGL((k_lloyd_inertia<D, uint8_t>), dim3(nblocks), dim3(256), 0, s, (const uint8_t *)X, N, st, labels, partial); break;
+    case OFC_F32: hipLaunchKernelGGL((k_lloyd_inertia<D, float>), dim3(nblocks), dim3(256), 0, s, (const float *)X, N, st, labels, partial); break;
+    case OFC_F64: hipLaunchKernelGGL((k_lloyd_inertia<D, double>), dim3(nblocks), dim3(256), 0, s, (const double *)X, N, st, labels, partial); break;
+    default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_lloyd_inertia(const void *X, int dtype, int64_t N, int d, const LloydState *st,
+                         const uint8_t *labels, double *partial, int nblocks, hipStream_t s)
+{
+    int rc = OFC_OK;
+    OFC_D_SWITCH(d, { rc = launch_inertia_d<DD>(X, dtype, N, st, labels, partial, nblocks, s); })
+    return rc;
+}
+
+template <int D>
+static int launch_farthest_d(const void *X, int dtype, int64_t N, const LloydState *st, const double *c_old,
+                             const uint8_t *labels, const int64_t *excl, int n_excl, double *out,
+                             int nblocks, hipStream_t s)
+{
+    switch (dtype) {
+    case OFC_U8: hipLaunchKernelGGL((k_lloyd_farthest<D, uint8_t>), dim3(nblocks), dim3(256), 0, s, (const uint8_t *)X, N, st, c_old, labels, excl, n_excl, out); break;
+    case OFC_F32: hipLaunchKernelGGL((k_lloyd_farthest<D, float>), dim3(nblocks), dim3(256), 0, s, (const float *)X, N, st, c_old, labels, excl, n_excl, out); break;
+    case OFC_F64: hipLaunchKernelGGL((k_lloyd_farthest<D, double>), dim3(nblocks), dim3(256), 0, s, (const double *)X, N, st, c_old, labels, excl, n_excl, out); break;
+    default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_lloyd_farthest(const void *X, int dtype, int64_t N, int d, const LloydState *st,
+                          const double *c_old, const uint8_t *labels, const int64_t *excl, int n_excl,
+                          double *out, int nblocks, hipStream_t s)
+{
+    int rc = OFC_OK;
+    OFC_D_SWITCH(d, { rc = launch_farthest_d<DD>(X, dtype, N, st, c_old, labels, excl, n_excl, out, nblocks, s); })
+    return rc;
+}
+
+}  // namespace ofc

@@ -1,0 +1,125 @@
+"""GPU parity of the Lloyd kernels through the C ABI: bit-exact labels against the CPU oracle AND against
+the sklearn-generated goldens (fixed init), n_iter identical, centres <= 1e-9, inertia <= 1e-10 rel."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lloyd_goldens.npz"))
+CASES = sorted({k.split("/")[0] for k in Z.files if "/" in k})
+
+
+@pytest.fixture(scope="module")
+def KMeans():
+    from opticalflowclustering_amd.cluster import KMeans
+    return KMeans
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_fit_matches_sklearn_golden(KMeans, name):
+    X, C0 = Z[name + "/X"], Z[name + "/C0"]
+    km = KMeans(n_clusters=len(C0), init=C0, max_iter=int(Z[name + "/max_iter"]), tol=float(Z[name + "/tol"])).fit(X)
+    assert km.n_iter_ == int(Z[name + "/n_iter"])
+    assert np.array_equal(km.labels_, Z[name + "/labels"])
+    assert np.abs(km.cluster_centers_ - Z[name + "/centers"]).max() <= 1e-9
+    assert abs(km.inertia_ - float(Z[name + "/inertia"])) <= 1e-10 * float(Z[name + "/inertia"])
+    assert np.array_equal(km.predict(X), Z[name + "/predict"])
+
+
+@pytest.mark.parametrize("dtype,d,k,N", [(np.uint8, 4, 1, 2601), (np.uint8, 4, 3, 5852), (np.uint8, 4, 8, 23562),
+                                         (np.float32, 2, 5, 100003), (np.float32, 2, 2, 7), (np.float64, 3, 4, 4099),
+                                         (np.float32, 1, 3, 1000), (np.float64, 4, 12, 20000), (np.uint8, 3, 16, 9000)])
+def test_fit_matches_oracle(KMeans, dtype, d, k, N):
+    rng = np.random.default_rng(N + k)
+    if dtype == np.uint8:
+        X = rng.integers(0, 256, (N, d), dtype=np.uint8)
+        X[rng.random(N) < 0.6] = 0
+    else:
+        cen = rng.uniform(-5, 5, (k, d))
+        X = (cen[rng.integers(0, k, N)] + 0.7 * rng.standard_normal((N, d))).astype(dtype)
+    C0 = X[rng.choice(N, k, replace=False)].astype(np.float64) + (np.arange(k)[:, None] * 1e-3)
+    km = KMeans(n_clusters=k, init=C0).fit(X)
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, C0)
+    assert km.n_iter_ == n_iter
+    assert np.array_equal(km.labels_, lab)
+    assert np.abs(km.cluster_centers_ - cen).max() <= 1e-9
+    assert abs(km.inertia_ - inertia) <= 1e-10 * max(inertia, 1e-300)
+    assert np.array_equal(km.predict(X), O.kmeans_predict(X, cen))
+
+
+def test_two_empty_clusters_relocated(KMeans):
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((3000, 2))
+    C0 = np.array([[0.0, 0.0], [300.0, 300.0], [-400.0, 250.0], [0.5, 0.5]])
+    km = KMeans(n_clusters=4, init=C0).fit(X)
+    cen, lab, _, n_iter = O.kmeans_fit(X, C0)
+    assert km.n_iter_ == n_iter and np.array_equal(km.labels_, lab)
+    assert np.abs(km.cluster_centers_ - cen).max() <= 1e-9
+    assert np.bincount(lab, minlength=4).min() > 0
+
+
+def test_duplicate_points_more_clusters_than_distinct(KMeans):
+    X = np.zeros((50, 4), np.uint8)
+    X[25:] = 7
+    C0 = np.array([[0, 0, 0, 0], [7, 7, 7, 7], [3, 3, 3, 3.0]])
+    km = KMeans(n_clusters=3, init=C0).fit(X)
+    cen, lab, _, n_iter = O.kmeans_fit(X, C0)
+    assert km.n_iter_ == n_iter and np.array_equal(km.labels_, lab)
+    assert np.allclose(km.cluster_centers_, cen, atol=1e-12)
+
+
+def test_errors(KMeans):
+    with pytest.raises(ValueError):
+        KMeans(n_clusters=3, init=np.zeros((3, 4))).fit(np.zeros((2, 4), np.uint8))
+    with pytest.raises(ValueError):
+        KMeans(n_clusters=2, init=np.zeros((3, 4))).fit(np.zeros((9, 4), np.uint8))
+    from opticalflowclustering_amd._lib import OfcError
+    with pytest.raises(OfcError):
+        KMeans(n_clusters=17).fit(np.random.default_rng(0).random((100, 2)))     # k > 16: outside kernel range
+
+
+def test_caller_data_untouched_and_seeded_init_reproducible(KMeans):
+    rng = np.random.default_rng(3)
+    X = rng.integers(0, 256, (4000, 4), dtype=np.uint8)
+    X0 = X.copy()
+    a = KMeans(n_clusters=3).fit(X)
+    b = KMeans(n_clusters=3).fit(X)
+    assert np.array_equal(X, X0)
+    assert np.array_equal(a.labels_, b.labels_) and np.array_equal(a.cluster_centers_, b.cluster_centers_)
+
+
+def test_full_size_properties_uv(KMeans):
+    """one 1080p frame of (u,v) vectors (cfg2 unit): size-independent properties instead of the oracle:
+    labels == argmin distance to the returned centres, centres == mean of their members, inertia consistent."""
+    rng = np.random.default_rng(11)
+    N = 1920 * 1080
+    vel = rng.uniform(-4, 4, (5, 2))
+    X = (vel[rng.integers(0, 5, N)] + 0.3 * rng.standard_normal((N, 2))).astype(np.float32)
+    C0 = X[rng.choice(N, 5, replace=False)].astype(np.float64)
+    km = KMeans(n_clusters=5, init=C0).fit(X)
+    Xd = X.astype(np.float64)
+    d2 = ((Xd[:, None, :] - km.cluster_centers_[None]) ** 2).sum(-1)
+    near = d2.argmin(1)
+    margin = np.sort(d2, 1)
+    amb = (margin[:, 1] - margin[:, 0]) < 1e-9
+    assert np.array_equal(near[~amb], km.labels_[~amb])
+    for j in range(5):
+        assert np.abs(Xd[km.labels_ == j].mean(0) - km.cluster_centers_[j]).max() < 1e-9 or km.n_iter_ == 300
+    assert abs(d2[np.arange(N), km.labels_].sum() - km.inertia_) <= 1e-9 * km.inertia_
+
+
+def test_dist_world1_allreduce():
+    """RCCL plumbing with a 1-rank communicator on the one GPU of the box"""
+    import ctypes as C
+    from opticalflowclustering_amd import _lib
+    lib = _lib.load()
+    uid = np.zeros(128, np.uint8)
+    _lib.check(lib.ofc_dist_unique_id(_lib.ptr(uid)))
+    _lib.check(lib.ofc_dist_init(0, 0, 1, _lib.ptr(uid)))
+    buf = _lib.DeviceBuffer(8 * 5).upload(np.arange(5, dtype=np.float64))
+    _lib.check(lib.ofc_dist_allreduce_f64(0, C.c_void_p(buf.ptr), 5))
+    assert np.array_equal(buf.download((5,), np.float64), np.arange(5.0))
+    _lib.check(lib.ofc_dist_finalize())
