@@ -193,6 +193,8 @@ struct PolyArgs {
     double ig11, ig03, ig33, ig55;
 };
 
+// TAG only gives the bench hook's launches their own symbol in rocprof's kernel statistics
+template <int TAG>
 __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
                                                  PolyArgs p)
 {
@@ -306,7 +308,7 @@ int polyexp_default_rows(int W, int H, int nimg)
 }
 
 int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
-                   int rows_per_block, hipStream_t s)
+                   int rows_per_block, hipStream_t s, bool bench_tag)
 {
     PolyArgs a;
     a.W = W; a.H = H;
@@ -315,7 +317,8 @@ int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyC
     for (int i = 0; i <= PE_N; i++) { a.g[i] = c.g[i]; a.xg[i] = c.xg[i]; a.xxg[i] = c.xxg[i]; }
     a.ig11 = c.ig11; a.ig03 = c.ig03; a.ig33 = c.ig33; a.ig55 = c.ig55;
     dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
-    hipLaunchKernelGGL(k_polyexp, grid, dim3(256), 0, s, I, R, a);
+    if (bench_tag) hipLaunchKernelGGL(k_polyexp<1>, grid, dim3(256), 0, s, I, R, a);
+    else hipLaunchKernelGGL(k_polyexp<0>, grid, dim3(256), 0, s, I, R, a);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

@@ -124,15 +124,24 @@ __global__ __launch_bounds__(256) void k_colstats(const T *__restrict__ X, int64
     block_reduce_store<D>(acc, lds, partial + (size_t)blockIdx.x * D);
 }
 
-// fixed-order sum of per-block records: out[i] = sum_b partial[b][i]
-__global__ __launch_bounds__(256) void k_reduce_records(const double *__restrict__ partial, int nblocks,
-                                                        int nv, double *__restrict__ out)
+// fixed-order sum of per-block records: out[i] = sum_b partial[b][i].  1024 threads: component i is
+// summed by nstripes = 1024/nv threads over interleaved record subsets, then folded in stripe order.
+__global__ __launch_bounds__(1024) void k_reduce_records(const double *__restrict__ partial, int nblocks,
+                                                         int nv, double *__restrict__ out)
 {
-    const int i = threadIdx.x;
-    if (i >= nv) return;
+    __shared__ double lds[1024];
+    const int nstripes = 1024 / nv;
+    const int i = threadIdx.x % nv, st = threadIdx.x / nv;
     double a = 0;
-    for (int b = 0; b < nblocks; b++) a += partial[(size_t)b * nv + i];
-    out[i] = a;
+    if (st < nstripes)
+        for (int b = st; b < nblocks; b += nstripes) a += partial[(size_t)b * nv + i];
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double r = 0;
+        for (int q = 0; q < nstripes; q++) r += lds[q * nv + threadIdx.x];
+        out[threadIdx.x] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,7 +487,7 @@ int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const doub
 int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s)
 {
     if (nv > 256) { set_error("record too long"); return OFC_EINVAL; }
-    hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(256), 0, s, partial, nblocks, nv, out);
+    hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(1024), 0, s, partial, nblocks, nv, out);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

@@ -499,9 +499,9 @@ int ofc_bench_polyexp(int device, int W, int H, int n_images, int iters, int row
     hipEvent_t e0, e1;
     OFC_HIP(hipEventCreate(&e0));
     OFC_HIP(hipEventCreate(&e1));
-    for (int w = 0; w < 2; w++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s));
+    for (int w = 0; w < 2; w++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s, true));
     OFC_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; i++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s));
+    for (int i = 0; i < iters; i++) OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), n_images, W, H, pc, rows_per_block, s, true));
     OFC_HIP(hipEventRecord(e1, s));
     OFC_HIP(hipEventSynchronize(e1));
     float ms = 0;

@@ -88,7 +88,7 @@ int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
                        const LevelGeom &g, hipStream_t s);
 // I: [nimg][H][W] f32 -> R: [nimg][5][H][W] f32 (planar)
 int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
-                   int rows_per_block, hipStream_t s);
+                   int rows_per_block, hipStream_t s, bool bench_tag = false);
 // R0 = R + pair*strideR, R1 = R0 + strideR (consecutive frames); flow [npair][H][W][2]; M [npair][5][H][W]
 int launch_update_matrices(const float *R0, const float *R1, size_t pair_stride_R,
                            const float *flow, float *M, int npair, int W, int H, hipStream_t s);

@@ -1,0 +1,76 @@
+"""Device-resident clip pipeline (BASELINE.json configs[2]/[3]): a clip's frames sit in HBM, dense
+Farneback flow is computed for every consecutive pair in batches, and Lloyd's k-means runs over the
+per-pixel (u,v) vectors of the whole clip without the flow ever leaving the device.  With a
+communicator (dist.py) each rank owns a contiguous range of pairs (plus the one-frame halo) and the
+Lloyd partial sums are all-reduced over RCCL once per iteration."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceBuffer, FbParams, check, load
+from .cluster import kmeans_fit_dev
+from .flow import FlowEngine
+
+
+def shard_pairs(n_pairs, world, rank):
+    """contiguous ranges of pair indices, sizes differing by at most one"""
+    base, rem = divmod(n_pairs, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class ClipPipeline:
+    def __init__(self, W, H, n_frames_local, batch_pairs=16, params=None, device=0):
+        self.W, self.H, self.device = W, H, device
+        self.n_frames = int(n_frames_local)
+        self.n_pairs = self.n_frames - 1
+        self.batch = max(1, min(int(batch_pairs), self.n_pairs))
+        self.engine = FlowEngine(W, H, params or FbParams(), max_batch=self.batch, device=device)
+        P = W * H
+        self.frames = DeviceBuffer(self.n_frames * P, device)
+        self.flows = DeviceBuffer(self.n_pairs * P * 8, device)
+        self.labels = DeviceBuffer(self.n_pairs * P, device)
+
+    def synth(self, t0=0, seed=0):
+        """fill the resident clip with synthetic frames t0 .. t0+n_frames-1"""
+        check(load().ofc_synth_frames_dev(self.device, C.c_void_p(self.frames.ptr), self.W, self.H,
+                                          self.n_frames, t0, seed))
+
+    def upload_frames(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.shape == (self.n_frames, self.H, self.W)
+        self.frames.upload(frames)
+
+    def run_flow(self, sync=True):
+        P = self.W * self.H
+        for p0 in range(0, self.n_pairs, self.batch):
+            n = min(self.batch, self.n_pairs - p0)
+            self.engine.calc_frames_dev(self.frames.ptr + p0 * P, n + 1, self.flows.ptr + p0 * P * 8, sync=False)
+        if sync:
+            self.engine.sync()
+
+    def run_kmeans(self, init, max_iter=300, tol=1e-4):
+        """Lloyd over all local (u,v) vectors (global when a communicator is active).
+        -> centers (k,2), inertia, n_iter"""
+        self.engine.sync()
+        N = self.n_pairs * self.W * self.H
+        return kmeans_fit_dev(self.flows.ptr, _lib.F32, N, 2, init, max_iter, tol, self.labels.ptr, self.device)
+
+    def sample_uv(self, idx):
+        """host copy of a few (u,v) rows (for choosing the initial centres)"""
+        out = np.empty((len(idx), 2), np.float32)
+        for i, j in enumerate(idx):
+            out[i] = self.flows.download((2,), np.float32, offset=int(j) * 8)
+        return out
+
+    def flows_host(self):
+        return self.flows.download((self.n_pairs, self.H, self.W, 2), np.float32)
+
+    def labels_host(self):
+        return self.labels.download((self.n_pairs, self.H, self.W), np.uint8)
+
+    def close(self):
+        self.engine.close()
+        for b in (self.frames, self.flows, self.labels):
+            b.free()
