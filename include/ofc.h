@@ -95,6 +95,14 @@ int ofc_flow_sync(ofc_flow_t *f);
  * frame; the first push returns OFC_ENOTREADY and writes nothing. */
 int ofc_flow_push_gray(ofc_flow_t *f, const uint8_t *gray, float *flow_out);
 
+/* ComputeOpticalFLow.compute (computeOpticalFlowModule.py:18-36) in one call: BGR frame (host) ->
+ * BGR2GRAY on the device -> flow against the previous frame -> HSV-coded BGR visualisation.  The first
+ * push stores the frame and returns OFC_ENOTREADY.  vis_out (HxWx3 u8), mean_mag, flow_out (HxWx2 f32)
+ * may each be NULL.  The visualisation also stays resident: ofc_flow_last_vis_dev(). */
+int ofc_flow_push_bgr(ofc_flow_t *f, const uint8_t *bgr, uint8_t *vis_out, float *mean_mag,
+                      float *flow_out);
+int ofc_flow_last_vis_dev(ofc_flow_t *f, const uint8_t **vis_dev);
+
 /* ---- single stages, host buffers (parity-test / bench hooks; interleaved layouts as OpenCV's
  *      internals so they compare 1:1 with the oracle) ---- */
 /* u8 frame -> f32 pyramid image of level k (GaussianBlur at full res + INTER_LINEAR resize) */
@@ -126,6 +134,11 @@ int ofc_bgr2gray(int device, const uint8_t *bgr, int W, int H, uint8_t *gray);
 int ofc_flow_to_bgr(int device, const float *flow, int W, int H, uint8_t *bgr, float *mean_mag);
 int ofc_flow_to_bgr_dev(int device, const float *flow_dev, int W, int H, int n_frames,
                         uint8_t *bgr_dev, float *mean_mag_dev);
+/* cvtColor(BGR2HSV) u8, H in [0,180) (KmeanGrids.py:86,336; color_kmeans.py:121) */
+int ofc_bgr2hsv(int device, const uint8_t *bgr, int64_t npix, uint8_t *hsv);
+/* preprocess_image (KmeanGrids.py:269-286, color_kmeans.py:35-52): per channel <thresh -> 0,
+ * alpha = 255 where BGR2GRAY > 0; HxWx3 u8 -> HxWx4 u8 (channel order kept as given) */
+int ofc_preprocess_rgba(int device, const uint8_t *img3, int64_t npix, int thresh, uint8_t *rgba);
 /* overlayGridAndComputeAvgColor (KmeanGrids.py:52-113): per-cell mean BGR -> u8 -> BGR2HSV.
  * mean_bgr, hsv: rows*cols x 3 u8 */
 int ofc_grid_cell_means(int device, const uint8_t *bgr, int W, int H, int rows, int cols,
@@ -150,6 +163,26 @@ int ofc_kmeans_predict(int device, const void *X, int dtype, int64_t N, int d, i
 int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k,
                        const double *init, int max_iter, double tol_rel, double *centers,
                        uint8_t *labels_dev, double *inertia, int *n_iter);
+/* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same
+ * kernels, one pass per call, records returned to the host so that ANY collective (RCCL, or
+ * torch.distributed/gloo across nodes) can combine the shards.  X_dev is this rank's shard. ---- */
+/* pass 0: out[f] = sum_i x[i][f]; pass 1: out[f] = sum_i (x[i][f]-mean[f])^2 */
+int ofc_lloyd_colstats_dev(int device, const void *X_dev, int dtype, int64_t N, int d, const double *mean,
+                           int pass, double *out);
+/* one E-step (+ M-step accumulation when accumulate != 0) against the CENTRED centres centers_c (k x d):
+ * labels_dev (N x u8, 0xFF = unassigned) is read and rewritten; record = [k*d sums of (x-mean) | k counts |
+ * number of labels that changed] */
+int ofc_lloyd_step_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                       const double *centers_c, uint8_t *labels_dev, int accumulate, double *record);
+/* sum_i ||(x_i - mean) - centers_c[label_i]||^2 */
+int ofc_lloyd_inertia_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                          const double *centers_c, const uint8_t *labels_dev, double *inertia);
+/* the sample farthest from its assigned (old) centre, skipping the local indices in excl[0..n_excl):
+ * *dist2 (-1 if none), *index, x_c[d] = its centred coordinates, *label */
+int ofc_lloyd_farthest_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                           const double *centers_c, const uint8_t *labels_dev, const int64_t *excl, int n_excl,
+                           double *dist2, int64_t *index, double *x_c, int *label);
+
 /* many small independent problems in one launch (the per-grid-cell shape of KmeanGrids.py:376-392):
  * problem p owns rows [offsets[p], offsets[p+1]) of X (u8, d = 4); init/centers: P x k x d f64;
  * counts: P x k i32 = np.bincount(predict(X)); labels may be NULL. */
@@ -164,6 +197,12 @@ int ofc_kmeans_fit_batched(int device, const uint8_t *X, const int64_t *offsets,
 int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int cols, int k,
                     const double *init, int max_iter, double tol_rel, int channel_order,
                     double *centers, uint8_t *hsv);
+
+/* same on device-resident frames (n_frames x HxWx3 u8): centers n_frames*cells x 4 f64 and
+ * hsv n_frames*cells x 3 u8 are HOST buffers; init is NULL (device seeding) or host n_frames*cells*k*4 */
+int ofc_grid_kmeans_dev(int device, const uint8_t *bgr_dev, int W, int H, int n_frames, int rows,
+                        int cols, int k, const double *init, int max_iter, double tol_rel,
+                        int channel_order, double *centers, uint8_t *hsv);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU; frames (hence (u,v) points) are sharded by rank; the only

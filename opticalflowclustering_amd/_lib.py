@@ -54,6 +54,8 @@ _PROTOS = {
     "ofc_flow_calc_frames_dev": ([_vp, _vp, _i, _vp], _i),
     "ofc_flow_sync": ([_vp], _i),
     "ofc_flow_push_gray": ([_vp, _vp, _vp], _i),
+    "ofc_flow_push_bgr": ([_vp, _vp, _vp, C.POINTER(_f), _vp], _i),
+    "ofc_flow_last_vis_dev": ([_vp, C.POINTER(_vp)], _i),
     "ofc_level_image": ([_i, _vp, _i, _i, C.POINTER(FbParams), _i, _vp, _ip, _ip], _i),
     "ofc_polyexp": ([_i, _vp, _i, _i, _i, _d, _vp], _i),
     "ofc_update_matrices": ([_i, _vp, _vp, _vp, _i, _i, _vp], _i),
@@ -63,12 +65,19 @@ _PROTOS = {
     "ofc_bgr2gray": ([_i, _vp, _i, _i, _vp], _i),
     "ofc_flow_to_bgr": ([_i, _vp, _i, _i, _vp, C.POINTER(_f)], _i),
     "ofc_flow_to_bgr_dev": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
+    "ofc_bgr2hsv": ([_i, _vp, _i64, _vp], _i),
+    "ofc_preprocess_rgba": ([_i, _vp, _i64, _i, _vp], _i),
     "ofc_grid_cell_means": ([_i, _vp, _i, _i, _i, _i, _vp, _vp], _i),
     "ofc_kmeans_fit": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, C.POINTER(_d), _ip], _i),
     "ofc_kmeans_predict": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp], _i),
     "ofc_kmeans_fit_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, C.POINTER(_d), _ip], _i),
+    "ofc_lloyd_colstats_dev": ([_i, _vp, _i, _i64, _i, _vp, _i, _vp], _i),
+    "ofc_lloyd_step_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
+    "ofc_lloyd_inertia_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, C.POINTER(_d)], _i),
+    "ofc_lloyd_farthest_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_d), C.POINTER(_i64), _vp, _ip], _i),
     "ofc_kmeans_fit_batched": ([_i, _vp, _vp, _i, _i, _i, _vp, _i, _d, _vp, _vp, _vp, _vp], _i),
     "ofc_grid_kmeans": ([_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _vp], _i),
+    "ofc_grid_kmeans_dev": ([_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _vp], _i),
     "ofc_dist_unique_id": ([_vp], _i),
     "ofc_dist_init": ([_i, _i, _i, _vp], _i),
     "ofc_dist_allreduce_f64": ([_i, _vp, _i], _i),

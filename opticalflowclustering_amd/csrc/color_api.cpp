@@ -24,6 +24,32 @@ int ofc_bgr2gray(int device, const uint8_t *bgr, int W, int H, uint8_t *gray)
     return OFC_OK;
 }
 
+int ofc_bgr2hsv(int device, const uint8_t *bgr, int64_t npix, uint8_t *hsv)
+{
+    OFC_REQUIRE(bgr && hsv && npix >= 1, "bad arguments");
+    OFC_TRY(ensure_device(device));
+    DevBuf a, b;
+    OFC_TRY(a.alloc((size_t)npix * 3));
+    OFC_TRY(b.alloc((size_t)npix * 3));
+    OFC_HIP(hipMemcpy(a.p, bgr, (size_t)npix * 3, hipMemcpyHostToDevice));
+    OFC_TRY(launch_bgr2hsv(a.as<uint8_t>(), b.as<uint8_t>(), npix, nullptr));
+    OFC_HIP(hipMemcpy(hsv, b.p, (size_t)npix * 3, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_preprocess_rgba(int device, const uint8_t *img3, int64_t npix, int thresh, uint8_t *rgba)
+{
+    OFC_REQUIRE(img3 && rgba && npix >= 1, "bad arguments");
+    OFC_TRY(ensure_device(device));
+    DevBuf a, b;
+    OFC_TRY(a.alloc((size_t)npix * 3));
+    OFC_TRY(b.alloc((size_t)npix * 4));
+    OFC_HIP(hipMemcpy(a.p, img3, (size_t)npix * 3, hipMemcpyHostToDevice));
+    OFC_TRY(launch_preprocess_rgba(a.as<uint8_t>(), b.as<uint8_t>(), npix, thresh, nullptr));
+    OFC_HIP(hipMemcpy(rgba, b.p, (size_t)npix * 4, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
 int ofc_flow_to_bgr_dev(int device, const float *flow_dev, int W, int H, int n_frames, uint8_t *bgr_dev,
                         float *mean_mag_dev)
 {
@@ -122,27 +148,26 @@ int ofc_kmeans_fit_batched(int device, const uint8_t *X, const int64_t *offsets,
     return OFC_OK;
 }
 
-int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int cols, int k, const double *init,
-                    int max_iter, double tol_rel, int channel_order, double *centers, uint8_t *hsv)
+int ofc_grid_kmeans_dev(int device, const uint8_t *bgr_dev, int W, int H, int n_frames, int rows, int cols,
+                        int k, const double *init, int max_iter, double tol_rel, int channel_order,
+                        double *centers, uint8_t *hsv)
 {
-    OFC_REQUIRE(bgr && centers && hsv, "null pointer");
-    OFC_REQUIRE(rows >= 1 && cols >= 1 && W >= cols && H >= rows && max_iter >= 1, "bad arguments");
+    OFC_REQUIRE(bgr_dev && centers && hsv, "null pointer");
+    OFC_REQUIRE(rows >= 1 && cols >= 1 && W >= cols && H >= rows && max_iter >= 1 && n_frames >= 1, "bad arguments");
     OFC_TRY(ensure_device(device));
-    const size_t P = (size_t)W * H, nc = (size_t)rows * cols;
+    const size_t nc = (size_t)rows * cols * n_frames;
     const int npts = (W / cols) * (H / rows);
     OFC_REQUIRE(npts >= k, "n_samples=%d should be >= n_clusters=%d.", npts, k);
-    DevBuf f, dInit, dDom, dHsv;
-    OFC_TRY(f.alloc(P * 3));
+    DevBuf dInit, dDom, dHsv;
     OFC_TRY(dDom.alloc(sizeof(double) * nc * 4));
     OFC_TRY(dHsv.alloc(nc * 3));
-    OFC_HIP(hipMemcpy(f.p, bgr, P * 3, hipMemcpyHostToDevice));
     if (init) {
         OFC_TRY(dInit.alloc(sizeof(double) * nc * k * 4));
         OFC_HIP(hipMemcpy(dInit.p, init, sizeof(double) * nc * k * 4, hipMemcpyHostToDevice));
     }
     BatchedArgs a;
     memset(&a, 0, sizeof(a));
-    a.bgr = f.as<uint8_t>(); a.W = W; a.H = H; a.rows = rows; a.cols = cols;
+    a.bgr = bgr_dev; a.W = W; a.H = H; a.rows = rows; a.cols = cols;
     a.channel_order = channel_order; a.thresh = 30;
     a.k = k; a.max_iter = max_iter; a.n_problems = (int)nc; a.tol_rel = tol_rel;
     a.init = init ? dInit.as<double>() : nullptr;
@@ -151,6 +176,19 @@ int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int 
     OFC_HIP(hipMemcpy(centers, dDom.p, sizeof(double) * nc * 4, hipMemcpyDeviceToHost));
     OFC_HIP(hipMemcpy(hsv, dHsv.p, nc * 3, hipMemcpyDeviceToHost));
     return OFC_OK;
+}
+
+int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int cols, int k, const double *init,
+                    int max_iter, double tol_rel, int channel_order, double *centers, uint8_t *hsv)
+{
+    OFC_REQUIRE(bgr && centers && hsv, "null pointer");
+    OFC_REQUIRE(W >= 1 && H >= 1, "bad size");
+    OFC_TRY(ensure_device(device));
+    DevBuf f;
+    OFC_TRY(f.alloc((size_t)W * H * 3));
+    OFC_HIP(hipMemcpy(f.p, bgr, (size_t)W * H * 3, hipMemcpyHostToDevice));
+    return ofc_grid_kmeans_dev(device, f.as<uint8_t>(), W, H, 1, rows, cols, k, init, max_iter, tol_rel,
+                               channel_order, centers, hsv);
 }
 
 int ofc_synth_frames_dev(int device, uint8_t *frames_dev, int W, int H, int n_frames, int t0, int seed)

@@ -32,6 +32,8 @@ __device__ __forceinline__ void bgr2hsv_u8(unsigned b, unsigned g, unsigned r, u
 }
 
 int launch_bgr2gray(const uint8_t *bgr, uint8_t *gray, int64_t npix, hipStream_t s);
+int launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, int64_t npix, hipStream_t s);
+int launch_preprocess_rgba(const uint8_t *img, uint8_t *rgba, int64_t npix, int thresh, hipStream_t s);
 int launch_flow_to_bgr(const float *flow, int W, int H, int nframes, uint8_t *bgr, float *mean_mag_dev,
                        double *partial, VisFrameStats *stats, hipStream_t s);
 int launch_grid_cell_means(const uint8_t *bgr, int W, int H, int nframes, int rows, int cols,

@@ -42,6 +42,45 @@ int launch_bgr2gray(const uint8_t *bgr, uint8_t *gray, int64_t npix, hipStream_t
     return OFC_OK;
 }
 
+__global__ __launch_bounds__(256) void k_bgr2hsv(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ hsv,
+                                                 int64_t npix)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    unsigned h, s, v;
+    bgr2hsv_u8(bgr[i * 3], bgr[i * 3 + 1], bgr[i * 3 + 2], h, s, v);
+    hsv[i * 3] = h; hsv[i * 3 + 1] = s; hsv[i * 3 + 2] = v;
+}
+
+int launch_bgr2hsv(const uint8_t *bgr, uint8_t *hsv, int64_t npix, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bgr2hsv, dim3((unsigned)cdiv64(npix, 256)), dim3(256), 0, s, bgr, hsv, npix);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// K10  preprocess_image: per-channel threshold, alpha from the grey value; 3 B in, 4 B out per pixel
+__global__ __launch_bounds__(256) void k_preprocess_rgba(const uint8_t *__restrict__ img, uint32_t *__restrict__ rgba,
+                                                         int64_t npix, int thresh)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    unsigned c0 = img[i * 3], c1 = img[i * 3 + 1], c2 = img[i * 3 + 2];
+    c0 = c0 < (unsigned)thresh ? 0u : c0;
+    c1 = c1 < (unsigned)thresh ? 0u : c1;
+    c2 = c2 < (unsigned)thresh ? 0u : c2;
+    const unsigned alpha = gray_of(c0, c1, c2) > 0 ? 255u : 0u;
+    rgba[i] = c0 | (c1 << 8) | (c2 << 16) | (alpha << 24);
+}
+
+int launch_preprocess_rgba(const uint8_t *img, uint8_t *rgba, int64_t npix, int thresh, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_preprocess_rgba, dim3((unsigned)cdiv64(npix, 256)), dim3(256), 0, s, img,
+                       reinterpret_cast<uint32_t *>(rgba), npix, thresh);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7/K8  flow -> BGR.  Pass 1: per-frame min/max of the magnitude + f64 sum (for np.mean(magnitude)).
 // Pass 2: recompute magnitude/angle, normalise, truncate, HSV2BGR.  8 B/px read twice + 3 B/px written.

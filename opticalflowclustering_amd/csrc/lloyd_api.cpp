@@ -263,6 +263,142 @@ int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int 
     return lloyd_fit_dev(device, X_dev, dtype, N, d, k, init, max_iter, tol_rel, centers, labels_dev, inertia, n_iter);
 }
 
+// ---- host-driven building blocks ----
+namespace {
+struct StepCtx {
+    DevBuf state, partial, tot, excl, far;
+    int nblocks = 1;
+    int init(int64_t N, int nv)
+    {
+        nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+        OFC_TRY(state.alloc(sizeof(LloydState)));
+        OFC_TRY(partial.alloc(sizeof(double) * (size_t)nblocks * std::max(nv, 2)));
+        OFC_TRY(tot.alloc(sizeof(double) * (nv + 8)));
+        OFC_HIP(hipMemset(state.p, 0, sizeof(LloydState)));
+        return OFC_OK;
+    }
+    int set(const double *mean, const double *centers_c, int k, int d)
+    {
+        LloydState *st = state.as<LloydState>();
+        if (mean) OFC_HIP(hipMemcpy(st->mean, mean, sizeof(double) * d, hipMemcpyHostToDevice));
+        if (centers_c) {
+            OFC_HIP(hipMemcpy(st->centers, centers_c, sizeof(double) * k * d, hipMemcpyHostToDevice));
+            OFC_TRY(launch_lloyd_set_centers(st, k, d, nullptr));
+        }
+        return OFC_OK;
+    }
+};
+int check_kd(int k, int d)
+{
+    if (d < 1 || k < 1 || d > LLOYD_DMAX || k > LLOYD_KMAX) {
+        set_error("k=%d, d=%d outside the kernels' range (k <= %d, d <= %d)", k, d, LLOYD_KMAX, LLOYD_DMAX);
+        return OFC_EUNSUPPORTED;
+    }
+    return OFC_OK;
+}
+}  // namespace
+
+int ofc_lloyd_colstats_dev(int device, const void *X_dev, int dtype, int64_t N, int d, const double *mean, int pass,
+                           double *out)
+{
+    OFC_REQUIRE(X_dev && out && N >= 0 && (pass == 0 || mean), "bad arguments");
+    OFC_TRY(check_kd(1, d));
+    OFC_TRY(ensure_device(device));
+    StepCtx c;
+    OFC_TRY(c.init(N, d));
+    OFC_TRY(c.set(pass ? mean : nullptr, nullptr, 1, d));
+    LloydState *st = c.state.as<LloydState>();
+    OFC_TRY(launch_lloyd_colstats(X_dev, dtype, N, d, st->mean, pass, c.partial.as<double>(), c.nblocks, nullptr));
+    OFC_TRY(launch_reduce_records(c.partial.as<double>(), c.nblocks, d, c.tot.as<double>(), nullptr));
+    OFC_HIP(hipMemcpy(out, c.tot.p, sizeof(double) * d, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_lloyd_step_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                       const double *centers_c, uint8_t *labels_dev, int accumulate, double *record)
+{
+    OFC_REQUIRE(X_dev && mean && centers_c && labels_dev && (record || !accumulate) && N >= 0, "bad arguments");
+    OFC_TRY(check_kd(k, d));
+    OFC_TRY(ensure_device(device));
+    const int kmax = lloyd_kmax(k), NV = kmax * d + kmax + 1;
+    StepCtx c;
+    OFC_TRY(c.init(N, NV));
+    OFC_TRY(c.set(mean, centers_c, k, d));
+    LloydState *st = c.state.as<LloydState>();
+    OFC_TRY(launch_lloyd_assign(X_dev, dtype, N, d, k, st, labels_dev, c.partial.as<double>(), c.nblocks, accumulate != 0, nullptr));
+    if (accumulate) {
+        OFC_TRY(launch_reduce_records(c.partial.as<double>(), c.nblocks, NV, c.tot.as<double>(), nullptr));
+        std::vector<double> t(NV);
+        OFC_HIP(hipMemcpy(t.data(), c.tot.p, sizeof(double) * NV, hipMemcpyDeviceToHost));
+        for (int j = 0; j < k; j++) {
+            for (int f = 0; f < d; f++) record[j * d + f] = t[j * d + f];
+            record[k * d + j] = t[kmax * d + j];
+        }
+        record[k * d + k] = t[kmax * d + kmax];
+    } else {
+        OFC_HIP(hipStreamSynchronize(nullptr));
+    }
+    return OFC_OK;
+}
+
+int ofc_lloyd_inertia_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                          const double *centers_c, const uint8_t *labels_dev, double *inertia)
+{
+    OFC_REQUIRE(X_dev && mean && centers_c && labels_dev && inertia && N >= 0, "bad arguments");
+    OFC_TRY(check_kd(k, d));
+    OFC_TRY(ensure_device(device));
+    StepCtx c;
+    OFC_TRY(c.init(N, 2));
+    OFC_TRY(c.set(mean, centers_c, k, d));
+    OFC_TRY(launch_lloyd_inertia(X_dev, dtype, N, d, c.state.as<LloydState>(), labels_dev, c.partial.as<double>(), c.nblocks, nullptr));
+    OFC_TRY(launch_reduce_records(c.partial.as<double>(), c.nblocks, 1, c.tot.as<double>(), nullptr));
+    OFC_HIP(hipMemcpy(inertia, c.tot.p, sizeof(double), hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_lloyd_farthest_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *mean,
+                           const double *centers_c, const uint8_t *labels_dev, const int64_t *excl, int n_excl,
+                           double *dist2, int64_t *index, double *x_c, int *label)
+{
+    OFC_REQUIRE(X_dev && mean && centers_c && labels_dev && dist2 && index && x_c && label && N >= 0, "bad arguments");
+    OFC_REQUIRE(n_excl >= 0 && n_excl <= LLOYD_KMAX && (n_excl == 0 || excl), "bad exclusion list");
+    OFC_TRY(check_kd(k, d));
+    OFC_TRY(ensure_device(device));
+    StepCtx c;
+    OFC_TRY(c.init(N, 2));
+    OFC_TRY(c.set(mean, centers_c, k, d));
+    OFC_TRY(c.excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
+    if (n_excl) OFC_HIP(hipMemcpy(c.excl.p, excl, sizeof(int64_t) * n_excl, hipMemcpyHostToDevice));
+    LloydState *st = c.state.as<LloydState>();
+    OFC_TRY(launch_lloyd_farthest(X_dev, dtype, N, d, st, st->centers, labels_dev, c.excl.as<int64_t>(), n_excl,
+                                  c.partial.as<double>(), c.nblocks, nullptr));
+    std::vector<double> blk(2 * c.nblocks);
+    OFC_HIP(hipMemcpy(blk.data(), c.partial.p, sizeof(double) * 2 * c.nblocks, hipMemcpyDeviceToHost));
+    double best = -1;
+    int64_t bi = -1;
+    for (int b = 0; b < c.nblocks; b++) {
+        const double v = blk[2 * b];
+        const int64_t i = (int64_t)blk[2 * b + 1];
+        if (i < 0) continue;
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    *dist2 = bi >= 0 ? best : -1;
+    *index = bi;
+    *label = -1;
+    if (bi >= 0) {
+        unsigned char raw[LLOYD_DMAX * 8];
+        uint8_t lab;
+        OFC_HIP(hipMemcpy(raw, (const char *)X_dev + (size_t)bi * d * dtype_size(dtype), d * dtype_size(dtype), hipMemcpyDeviceToHost));
+        OFC_HIP(hipMemcpy(&lab, labels_dev + bi, 1, hipMemcpyDeviceToHost));
+        for (int f = 0; f < d; f++) {
+            double v = dtype == OFC_U8 ? (double)raw[f] : dtype == OFC_F32 ? (double)((float *)raw)[f] : ((double *)raw)[f];
+            x_c[f] = v - mean[f];
+        }
+        *label = lab;
+    }
+    return OFC_OK;
+}
+
 int ofc_kmeans_fit(int device, const void *X, int dtype, int64_t N, int d, int k, const double *init,
                    int max_iter, double tol_rel, double *centers, int32_t *labels, double *inertia, int *n_iter)
 {

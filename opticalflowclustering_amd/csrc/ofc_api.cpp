@@ -1,6 +1,6 @@
 // ofc_api.cpp -- C ABI of libofc.so, part 1: runtime plumbing and the Farneback flow engine.
 // Declared in include/ofc.h (which cites the reference call each entry point replaces).
-#include "ofc_common.h"
+#include "color_common.h"
 
 #include <cfloat>
 #include <cmath>
@@ -223,6 +223,7 @@ struct ofc_flow {
     DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
+    DevBuf bgr_in, vis, vis_partial, vis_stats, mean_mag;   // ofc_flow_push_bgr
 };
 
 namespace ofc {
@@ -359,6 +360,49 @@ int ofc_flow_push_gray(ofc_flow_t *f, const uint8_t *gray, float *flow_out)
     OFC_TRY(flow_run(f, fr, 2, f->flow1.as<float>()));
     OFC_HIP(hipMemcpyAsync(flow_out, f->flow1.p, sizeof(float) * 2 * P0, hipMemcpyDeviceToHost, f->stream));
     OFC_HIP(hipStreamSynchronize(f->stream));
+    return OFC_OK;
+}
+
+int ofc_flow_push_bgr(ofc_flow_t *f, const uint8_t *bgr, uint8_t *vis_out, float *mean_mag, float *flow_out)
+{
+    OFC_REQUIRE(f && bgr, "null pointer");
+    OFC_TRY(ensure_device(f->device));
+    const size_t P0 = (size_t)f->W * f->H;
+    hipStream_t s = f->stream;
+    if (!f->bgr_in.p) {
+        OFC_TRY(f->bgr_in.alloc(P0 * 3 + 16));
+        OFC_TRY(f->vis.alloc(P0 * 3 + 16));
+        OFC_TRY(f->vis_partial.alloc(sizeof(double) * 3 * VIS_BLOCKS));
+        OFC_TRY(f->vis_stats.alloc(sizeof(VisFrameStats)));
+        OFC_TRY(f->mean_mag.alloc(sizeof(float)));
+    }
+    uint8_t *fr = f->frames2.as<uint8_t>();
+    OFC_HIP(hipMemcpyAsync(f->bgr_in.p, bgr, P0 * 3, hipMemcpyHostToDevice, s));
+    if (!f->have_prev) {
+        OFC_TRY(launch_bgr2gray(f->bgr_in.as<uint8_t>(), f->prev_gray.as<uint8_t>(), (int64_t)P0, s));
+        OFC_HIP(hipStreamSynchronize(s));
+        f->have_prev = true;
+        set_error("first frame pushed: no pair yet");
+        return OFC_ENOTREADY;
+    }
+    OFC_HIP(hipMemcpyAsync(fr, f->prev_gray.p, P0, hipMemcpyDeviceToDevice, s));
+    OFC_TRY(launch_bgr2gray(f->bgr_in.as<uint8_t>(), fr + P0, (int64_t)P0, s));
+    OFC_HIP(hipMemcpyAsync(f->prev_gray.p, fr + P0, P0, hipMemcpyDeviceToDevice, s));
+    OFC_TRY(flow_run(f, fr, 2, f->flow1.as<float>()));
+    OFC_TRY(launch_flow_to_bgr(f->flow1.as<float>(), f->W, f->H, 1, f->vis.as<uint8_t>(), f->mean_mag.as<float>(),
+                               f->vis_partial.as<double>(), f->vis_stats.as<VisFrameStats>(), s));
+    if (vis_out) OFC_HIP(hipMemcpyAsync(vis_out, f->vis.p, P0 * 3, hipMemcpyDeviceToHost, s));
+    if (mean_mag) OFC_HIP(hipMemcpyAsync(mean_mag, f->mean_mag.p, sizeof(float), hipMemcpyDeviceToHost, s));
+    if (flow_out) OFC_HIP(hipMemcpyAsync(flow_out, f->flow1.p, sizeof(float) * 2 * P0, hipMemcpyDeviceToHost, s));
+    OFC_HIP(hipStreamSynchronize(s));
+    return OFC_OK;
+}
+
+int ofc_flow_last_vis_dev(ofc_flow_t *f, const uint8_t **vis_dev)
+{
+    OFC_REQUIRE(f && vis_dev, "null pointer");
+    OFC_REQUIRE(f->vis.p, "no visualisation yet: call ofc_flow_push_bgr twice first");
+    *vis_dev = f->vis.as<uint8_t>();
     return OFC_OK;
 }
 

@@ -1,0 +1,169 @@
+"""GPU end-to-end tests of the reference-named entry points (ComputeOpticalFLow, computeOpticalFlow.py,
+color_kmeans.py, color_kmeansChange.py, KmeanGrids.py) against a pipeline assembled from the CPU oracle,
+and of the device-resident clip pipeline / host-driven sharded driver against the in-library fit."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from opticalflowclustering_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+K = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_cells.npz"))
+
+
+def make_video(W=700, H=420, T=4, seed=2):
+    p = synth.texture_params(seed)
+    rng = np.random.default_rng(seed)
+    frames = []
+    for t in range(T):
+        g = synth.frame(W, H, 1.1 * t, -0.6 * t, p)
+        bgr = np.stack([g, np.roll(g, 3, 1), 255 - g], -1)
+        bgr[rng.random((H, W)) < 0.01] = rng.integers(0, 256, 3)
+        frames.append(bgr.astype(np.uint8))
+    return np.stack(frames)
+
+
+def oracle_vis(prev_bgr, next_bgr):
+    flow = O.farneback(O.bgr2gray(prev_bgr), O.bgr2gray(next_bgr))
+    return O.flow_to_bgr(flow), flow
+
+
+def test_compute_optical_flow_class_matches_oracle():
+    from opticalflowclustering_amd.computeOpticalFlowModule import ComputeOpticalFLow
+    v = make_video()
+    cf = ComputeOpticalFLow(v[0])
+    for t in range(1, len(v)):
+        rgb, flow = cf.compute(v[t], return_flow=True)
+        (want, wm), wflow = oracle_vis(v[t - 1], v[t])
+        assert np.abs(flow - wflow).max() <= 1e-3
+        # the uint8 planes are truncations of float values: a 1e-7 flow difference may move a pixel across an
+        # integer boundary; require >= 99.9 % identical bytes and no byte off by more than the hue/value step
+        same = (rgb == want).mean()
+        assert same >= 0.999, same
+        assert abs(cf.last_mean_magnitude - wm) <= 1e-5 * wm
+        assert rgb.flags.owndata and rgb.flags.writeable
+    with pytest.raises(ValueError):
+        cf.compute(None)
+    cf.close()
+
+
+def test_compute_optical_flow_cli(tmp_path):
+    from opticalflowclustering_amd import computeOpticalFlow
+    v = make_video(T=3)
+    src = str(tmp_path / "clip.npy")
+    np.save(src, v)
+    computeOpticalFlow.main(["-i", src])
+    rows = list(csv.reader(open(src + "_opticalFlow.csv")))
+    assert rows[0] == ["", "Frame", "Average Magnitude"] and [r[1] for r in rows[1:]] == ["0", "1"]
+    for t, r in enumerate(rows[1:]):
+        (_, wm), _ = oracle_vis(v[t], v[t + 1])
+        assert abs(float(r[2]) - wm) <= 1e-5 * wm
+    data = open(src + "onlyOpticalflow.mp4", "rb").read()
+    assert data[:4] == b"RIFF" and data.count(b"00dc") >= 2
+    assert os.path.getsize(src + "_squares.png") > 0
+
+
+def test_color_kmeans_cli_k1_and_k3(tmp_path):
+    from PIL import Image
+    from opticalflowclustering_amd import color_kmeans
+    CELL = 200
+    rgb = K["cells_rgb"][0][CELL]
+    img_path = str(tmp_path / "cell.png")
+    Image.fromarray(rgb).save(img_path)
+    out = str(tmp_path / "out.csv")
+    color_kmeans.main(["-i", img_path, "-c", "1", "-f", out])
+    color_kmeans.main(["-i", img_path, "-c", "1", "-f", out])
+    rows = list(csv.reader(open(out)))
+    assert rows[0] == ["File name", "Cluster 1", "HSV Cluster 1", "Hue 0"] and len(rows) == 3
+    assert rows[1][0] == "cell.png" and int(rows[1][3]) == int(K["hue_kmeans_k1"][0][CELL])       # KAT-B value
+    X = O.preprocess_rgba(rgb.copy()).reshape(-1, 4)
+    cen, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
+    assert rows[1][1] == str(np.rint(cen[0]))
+    # k = 3: deterministic seeded-rows init, checked against the oracle run from the same init
+    img = color_kmeans.preprocess_image(color_kmeans.read_image(img_path))
+    c0, hsv0, clt = color_kmeans.dominant_cluster(img, 3)
+    from opticalflowclustering_amd.cluster import seeded_rows_init
+    oc, ol, _, on = O.kmeans_fit(X, seeded_rows_init(X, 3, 0))
+    assert clt.n_iter_ == on and np.array_equal(clt.labels_, ol)
+    dom = int(np.argmax(np.bincount(O.kmeans_predict(X, oc), minlength=3)))
+    assert np.array_equal(c0, np.rint(oc[dom]))
+
+
+def test_color_kmeans_change_reproduces_recorded_csv_rows(tmp_path):
+    """the disk path that produced OutCSV/601_bad_bounce_3.csv: dir/<frame>/<cell>.png -> rows"""
+    from PIL import Image
+    from opticalflowclustering_amd import color_kmeansChange
+    d = tmp_path / "OutImgs" / "vid" / "2"
+    d.mkdir(parents=True)
+    cells = list(range(0, 350, 7))
+    for c in cells:
+        Image.fromarray(K["cells_rgb"][0][c]).save(d / f"{c + 1}.png")
+    out = str(tmp_path / "o.csv")
+    color_kmeansChange.main(["-d", str(tmp_path / "OutImgs" / "vid"), "-c", "1", "-f", out])
+    rows = list(csv.reader(open(out)))
+    assert [r[0] for r in rows] == [f"2/{c + 1}.png" for c in cells]            # numeric order
+    assert [int(r[3]) for r in rows] == [int(K["hue_kmeans_k1"][0][c]) for c in cells]
+
+
+def test_kmean_grids_pipeline_matches_oracle(tmp_path, monkeypatch):
+    from opticalflowclustering_amd import KmeanGrids
+    v = make_video(W=700, H=420, T=3)
+    src = str(tmp_path / "clip.npy")
+    np.save(src, v)
+    monkeypatch.chdir(tmp_path)
+    KmeanGrids.main(["-d", "OutImgs/clip", "-c", "1", "-f", "x.csv", "--noyolo", "--nocontour", "--path", src])
+    rows = list(csv.reader(open(tmp_path / "OutCSV" / "clip.csv")))
+    assert rows[0] == [f"cell_{i}" for i in range(350)] and len(rows) == 3
+    for t in (1, 2):
+        (vis, _), _ = oracle_vis(v[t - 1], v[t])
+        want = []
+        for c in range(350):
+            X = O.preprocess_rgba(O.extract_cell(vis, c)).reshape(-1, 4)
+            cen, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
+            want.append(int(O.bgr2hsv(np.rint(cen[0])[:3].astype(np.uint8).reshape(1, 1, 3))[0, 0, 0]))
+        got = [int(x) for x in rows[t]]
+        # vis bytes may differ on a handful of truncation-boundary pixels (see above): the k=1 centre is a
+        # mean over 28x28 pixels, so at most a few cells sit on a rint boundary
+        assert sum(g != w for g, w in zip(got, want)) <= 3
+
+
+def test_overlay_grid_means_and_lines():
+    from opticalflowclustering_amd import KmeanGrids
+    rng = np.random.default_rng(9)
+    frame = rng.integers(0, 256, (420, 700, 3), dtype=np.uint8)
+    f0 = frame.copy()
+    KmeanGrids.image_dict.clear()
+    mean, hsv = KmeanGrids.overlayGridAndComputeAvgColor(5, frame, KmeanGrids.GRID_PARAMS)
+    om, oh = O.grid_cell_means(f0)
+    assert np.array_equal(mean, om) and np.array_equal(hsv, oh)
+    cell = KmeanGrids.image_dict["5/27"]                       # cell index 26 -> row 1, col 1
+    assert np.array_equal(cell, O.extract_cell(f0, 26))        # white row 0 / col 0, rest untouched
+    assert len(KmeanGrids.image_dict) == 350
+
+
+def test_clip_pipeline_and_sharded_driver_agree_with_library_fit():
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    from opticalflowclustering_amd.sharded import DeviceShard, fit_sharded
+    W, H, T = 480, 270, 6
+    pipe = ClipPipeline(W, H, T, batch_pairs=2)
+    pipe.synth(t0=0, seed=1)
+    pipe.run_flow()
+    flows = pipe.flows_host()
+    frames = pipe.frames.download((T, H, W), np.uint8)
+    for t in (0, T - 2):
+        want = O.farneback(frames[t], frames[t + 1])
+        assert np.abs(flows[t] - want).max() <= 1e-3
+    init = np.array([[-2.0, -2.0], [0.0, 0.0], [2.0, 2.0], [3.0, -1.0], [-3.0, 1.0]])
+    cen, inertia, n_iter = pipe.run_kmeans(init)
+    X = flows.reshape(-1, 2)
+    oc, ol, oi, on = O.kmeans_fit(X, init)
+    assert n_iter == on and np.array_equal(pipe.labels_host().ravel(), ol.astype(np.uint8))
+    assert np.abs(cen - oc).max() <= 1e-9 and abs(inertia - oi) <= 1e-10 * oi
+    shard = DeviceShard(pipe.flows.ptr, _lib.F32, len(X), 2)
+    c2, i2, n2 = fit_sharded(shard, init)
+    assert n2 == on and np.abs(c2 - oc).max() <= 1e-9 and abs(i2 - oi) <= 1e-10 * oi
+    pipe.close()
