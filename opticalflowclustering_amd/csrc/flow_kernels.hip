@@ -171,20 +171,33 @@ int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
 // ------------------------------------------------------------------------------------------------
 // K3  polynomial expansion (the north-star kernel).  24 B/px algorithmic: 4 read + 20 written.
 //
-// Work-group = 256 threads = 4 waves, output tile 240 columns x rows_per_block rows, walked in
-// chunks of 16 rows:
-//   vertical pass   thread <-> column (250 = 240 + 2x5 halo columns, replicate-clamped), two groups of
-//                   8 rows; each thread loads 18 input values straight from global (lanes <-> x:
-//                   coalesced) and produces the three f32 moments t0,t1,t2 for 8 rows with the
-//                   symmetric / antisymmetric tap pairing of the reference -> LDS [3][16][252]
-//   horizontal pass wave <-> row, lane <-> 4 consecutive x: 12 ds_read_b128, f64 accumulators b1..b6 as
-//                   the reference, 5 float4 stores per lane (16 B/lane, 1 KiB/wave-instruction).
-// 48 KB LDS per work-group -> 3 work-groups per CU.
+// Work-group = 256 threads = 4 waves, output strip 240 columns x rows_per_block rows, walked in chunks
+// of 8 rows:
+//   vertical pass   thread <-> column (250 = 240 + 2x5 halo columns, replicate-clamped).  Each thread keeps an
+//                   18-row register window of its column that slides down 8 rows per chunk; the 8 new rows
+//                   are requested right after the barrier (lanes <-> x: coalesced), so their latency hides
+//                   under the horizontal pass.  The window yields the three f32 moments t0,t1,t2 of 8 rows with
+//                   the symmetric / antisymmetric tap pairing of the reference -> LDS [3][8][256].
+//   horizontal pass wave <-> row, lane <-> 4 consecutive x: 12 ds_read_b128 (forced whole, see lds_read4),
+//                   accumulators as described in the loop, 5 float4 stores per lane (1 KiB/wave-instruction).
+// 24 KB LDS, 146 VGPRs -> 3 waves/SIMD.  Measured ceilings on MI355X for this traffic shape (tools/membench):
+// 1 read : 5 write streams = 4.9 TB/s; this kernel's compute alone (stores off) = 5.9 TB/s-equivalent.
 // ------------------------------------------------------------------------------------------------
+// 16-byte LDS read that hipcc may not narrow: a plain float4 load whose tail elements are unused is split into
+// ds_read2_b32 / ds_read2_b64, and with a 16-byte lane stride those are 8-way bank conflicts
+// (SQ_LDS_BANK_CONFLICT 1.3e8 cycles per launch before this).  volatile keeps the access whole -> ds_read_b128.
+__device__ __forceinline__ float4 lds_read4(const float *p)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const volatile v4f __attribute__((address_space(3))) * lds_v4f_ptr;
+    const v4f v = *(lds_v4f_ptr)(p);          // explicit LDS address space: ds_read_b128, not flat_load
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 constexpr int PE_N = 5;
 constexpr int PE_TX = 240;
 constexpr int PE_VW = PE_TX + 2 * PE_N;   // 250
-constexpr int PE_CH = 16;
+constexpr int PE_CH = 8;
 constexpr int PE_PITCH = 256;
 
 struct PolyArgs {
@@ -195,7 +208,7 @@ struct PolyArgs {
 
 // TAG only gives the bench hook's launches their own symbol in rocprof's kernel statistics
 template <int TAG>
-__global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
+__global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
                                                  PolyArgs p)
 {
     __shared__ __align__(16) float t[3][PE_CH][PE_PITCH];
@@ -210,36 +223,38 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
     const int xc = min(max(x0 - PE_N + tid, 0), W - 1);   // this thread's (clamped) column
     const bool vec_ok = (W & 3) == 0;
 
+    // register window of this thread's column: rows yc-5 .. yc+12; slides down 8 rows per chunk, the 8 new
+    // rows are requested right after the barrier so that their HBM latency hides under the horizontal pass
+    float s[8 + 2 * PE_N], nxt[8];
+#pragma unroll
+    for (int j = 0; j < 8 + 2 * PE_N; j++)
+        s[j] = img[(size_t)min(max(y_begin - PE_N + j, 0), H - 1) * W + xc];
+
     for (int yc = y_begin; yc < y_end; yc += PE_CH) {
         // ---- vertical pass ----
         if (tid < PE_VW) {
 #pragma unroll
-            for (int rg = 0; rg < 2; rg++) {
-                const int yb = yc + 8 * rg;
-                float s[8 + 2 * PE_N];
+            for (int i = 0; i < 8; i++) {
+                float t0 = s[i + PE_N] * p.g[0], t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8 + 2 * PE_N; j++) {
-                    int yy = min(max(yb - PE_N + j, 0), H - 1);
-                    s[j] = img[(size_t)yy * W + xc];
+                for (int k = 1; k <= PE_N; k++) {
+                    float a = s[i + PE_N - k], b = s[i + PE_N + k];
+                    float pp = a + b;
+                    t0 = fmaf(p.g[k], pp, t0);
+                    t1 = fmaf(p.xg[k], b - a, t1);
+                    t2 = fmaf(p.xxg[k], pp, t2);
                 }
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float t0 = s[i + PE_N] * p.g[0], t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int k = 1; k <= PE_N; k++) {
-                        float a = s[i + PE_N - k], b = s[i + PE_N + k];
-                        float pp = a + b;
-                        t0 = fmaf(p.g[k], pp, t0);
-                        t1 = fmaf(p.xg[k], b - a, t1);
-                        t2 = fmaf(p.xxg[k], pp, t2);
-                    }
-                    t[0][8 * rg + i][tid] = t0;
-                    t[1][8 * rg + i][tid] = t1;
-                    t[2][8 * rg + i][tid] = t2;
-                }
+                t[0][i][tid] = t0;
+                t[1][i][tid] = t1;
+                t[2][i][tid] = t2;
             }
         }
         __syncthreads();
+        if (yc + PE_CH < y_end) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                nxt[j] = img[(size_t)min(yc + PE_CH + PE_N + j, H - 1) * W + xc];
+        }
         // ---- horizontal pass ----
         for (int rr = wave; rr < PE_CH; rr += 4) {
             const int y = yc + rr;
@@ -249,9 +264,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
                 float a0[16], a1[16], a2[16];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    float4 v0 = *reinterpret_cast<const float4 *>(&t[0][rr][4 * lane + 4 * q]);
-                    float4 v1 = *reinterpret_cast<const float4 *>(&t[1][rr][4 * lane + 4 * q]);
-                    float4 v2 = *reinterpret_cast<const float4 *>(&t[2][rr][4 * lane + 4 * q]);
+                    const float4 v0 = lds_read4(&t[0][rr][4 * lane + 4 * q]);
+                    const float4 v1 = lds_read4(&t[1][rr][4 * lane + 4 * q]);
+                    const float4 v2 = lds_read4(&t[2][rr][4 * lane + 4 * q]);
                     a0[4 * q] = v0.x; a0[4 * q + 1] = v0.y; a0[4 * q + 2] = v0.z; a0[4 * q + 3] = v0.w;
                     a1[4 * q] = v1.x; a1[4 * q + 1] = v1.y; a1[4 * q + 2] = v1.z; a1[4 * q + 3] = v1.w;
                     a2[4 * q] = v2.x; a2[4 * q + 1] = v2.y; a2[4 * q + 2] = v2.z; a2[4 * q + 3] = v2.w;
@@ -260,23 +275,27 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     const int c = o + PE_N;
-                    double b1 = (double)(a0[c] * p.g[0]), b2 = 0, b3 = (double)(a1[c] * p.g[0]),
-                           b4 = 0, b5 = (double)(a2[c] * p.g[0]), b6 = 0;
+                    // b1, b4, b5 feed the second-derivative coefficients, where b1*ig03 cancels against b4|b5*ig33:
+                    // f64 accumulators exactly as the reference.  b2, b3, b6 (first derivatives and the mixed term)
+                    // are 5-term sums without cancellation: accumulated in f32 (<= ~3 ulp vs the f64 sum), which
+                    // removes 40 % of the f64-rate instructions of this VALU-bound pass.
+                    double b1 = (double)(a0[c] * p.g[0]), b4 = 0, b5 = (double)(a2[c] * p.g[0]);
+                    float b2 = 0.f, b3 = a1[c] * p.g[0], b6 = 0.f;
 #pragma unroll
                     for (int k = 1; k <= PE_N; k++) {
                         double tg = (double)(a0[c + k] + a0[c - k]);
                         b1 = fma(tg, (double)p.g[k], b1);
                         b4 = fma(tg, (double)p.xxg[k], b4);
-                        b2 += (double)((a0[c + k] - a0[c - k]) * p.xg[k]);
-                        b3 += (double)((a1[c + k] + a1[c - k]) * p.g[k]);
-                        b6 += (double)((a1[c + k] - a1[c - k]) * p.xg[k]);
+                        b2 = fmaf(a0[c + k] - a0[c - k], p.xg[k], b2);
+                        b3 = fmaf(a1[c + k] + a1[c - k], p.g[k], b3);
+                        b6 = fmaf(a1[c + k] - a1[c - k], p.xg[k], b6);
                         b5 += (double)((a2[c + k] + a2[c - k]) * p.g[k]);
                     }
-                    r1[o] = (float)(b2 * p.ig11);
-                    r0[o] = (float)(b3 * p.ig11);
+                    r1[o] = b2 * (float)p.ig11;
+                    r0[o] = b3 * (float)p.ig11;
                     r3[o] = (float)(b1 * p.ig03 + b4 * p.ig33);
                     r2[o] = (float)(b1 * p.ig03 + b5 * p.ig33);
-                    r4[o] = (float)(b6 * p.ig55);
+                    r4[o] = b6 * (float)p.ig55;
                 }
                 float *o0 = out + (size_t)y * W + xo;
                 if (vec_ok) {   // W % 4 == 0 -> xo+3 < W and 16-B aligned
@@ -296,14 +315,21 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, fl
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2 * PE_N; j++) s[j] = s[j + 8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[2 * PE_N + j] = nxt[j];
     }
 }
 
+
 int polyexp_default_rows(int W, int H, int nimg)
 {
+    // 64-row strips amortise the 10-row window warm-up (1.16x input reads); shrink them only when the
+    // launch would not give every CU a few work-groups
     int tiles_x = cdiv(W, PE_TX);
     int rows = 64;
-    while (rows > PE_CH && (int64_t)tiles_x * cdiv(H, rows) * nimg < 2048) rows >>= 1;
+    while (rows > PE_CH && (int64_t)tiles_x * cdiv(H, rows) * nimg < 1024) rows >>= 1;
     return rows;
 }
 
@@ -312,10 +338,10 @@ int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyC
 {
     PolyArgs a;
     a.W = W; a.H = H;
-    if (rows_per_block <= 0) rows_per_block = polyexp_default_rows(W, H, nimg);
-    a.rows_per_block = cdiv(rows_per_block, PE_CH) * PE_CH;
     for (int i = 0; i <= PE_N; i++) { a.g[i] = c.g[i]; a.xg[i] = c.xg[i]; a.xxg[i] = c.xxg[i]; }
     a.ig11 = c.ig11; a.ig03 = c.ig03; a.ig33 = c.ig33; a.ig55 = c.ig55;
+    if (rows_per_block <= 0) rows_per_block = polyexp_default_rows(W, H, nimg);
+    a.rows_per_block = cdiv(rows_per_block, PE_CH) * PE_CH;
     dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
     if (bench_tag) hipLaunchKernelGGL(k_polyexp<1>, grid, dim3(256), 0, s, I, R, a);
     else hipLaunchKernelGGL(k_polyexp<0>, grid, dim3(256), 0, s, I, R, a);
