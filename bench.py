@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="frame pairs per flow launch sequence")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs per flow launch sequence")
     ap.add_argument("--frames", type=int, default=CLIP_FRAMES, help="clip length (default = the named config)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()

@@ -12,6 +12,8 @@
 // bit for bit; polyexp and the box filter use FMAs / exact f64 sums (differences ~1e-7 relative).
 #include "ofc_common.h"
 
+#include <algorithm>
+
 namespace ofc {
 
 // ------------------------------------------------------------------------------------------------
@@ -354,46 +356,58 @@ int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyC
 // 68 B/px algorithmic (20 R0 + 20 R1 + 8 flow read, 20 M written); gather-coalesced because the
 // flow is smooth.  Contraction off: bit-exact with the oracle.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R0b,
-                                                         const float *__restrict__ R1b,
-                                                         size_t pair_stride_R,
-                                                         const float *__restrict__ flowb,
-                                                         float *__restrict__ Mb, int W, int H)
+// the per-pixel arithmetic of FarnebackUpdateMatrices, split into a branch-free LOAD
+// part (so that a caller can issue the gathers of several pixels back to back: a load inside a divergent
+// branch cannot be hoisted by the compiler and would serialise full memory latencies) and a pure-ALU part
+// with contraction off -> bit-exact with the oracle.
+struct UmIn {
+    float r0[5];        // R0 at the pixel
+    float g[4][5];      // R1 at the 4 bilinear taps (garbage-but-valid when out of range)
+    float fx, fy;
+    bool inr;
+};
+
+__device__ __forceinline__ void um_load(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
+                                        int W, int H, int x, int y, float2 fl, UmIn &u)
 {
 #pragma clang fp contract(off)
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const size_t plane = (size_t)W * H;
-    const float *R0 = R0b + blockIdx.z * pair_stride_R;
-    const float *R1 = R1b + blockIdx.z * pair_stride_R;
-    const float2 fl = reinterpret_cast<const float2 *>(flowb)[(size_t)blockIdx.z * plane + (size_t)y * W + x];
-    float *M = Mb + (size_t)blockIdx.z * 5 * plane;
     const size_t idx = (size_t)y * W + x;
-    const float dx = fl.x, dy = fl.y;
-    float fx = (float)x + dx, fy = (float)y + dy;
+    float fx = (float)x + fl.x, fy = (float)y + fl.y;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    fx -= (float)x1; fy -= (float)y1;
+    u.fx = fx - (float)x1;
+    u.fy = fy - (float)y1;
+    u.inr = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
+    const float *p = R1 + (u.inr ? (size_t)y1 * W + x1 : 0);
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        u.g[0][c] = p[0]; u.g[1][c] = p[1]; u.g[2][c] = p[W]; u.g[3][c] = p[W + 1];
+        p += plane;
+        u.r0[c] = R0[c * plane + idx];
+    }
+}
+
+__device__ __forceinline__ void um_math(const UmIn &u, int W, int H, int x, int y, float2 fl, float (&m)[5])
+{
+#pragma clang fp contract(off)
+    const float dx = fl.x, dy = fl.y, fx = u.fx, fy = u.fy;
     float r2, r3, r4, r5, r6;
-    const float R00 = R0[idx], R01 = R0[plane + idx], R02 = R0[2 * plane + idx],
-                R03 = R0[3 * plane + idx], R04 = R0[4 * plane + idx];
-    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
+    if (u.inr) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
                     a11 = fx * fy;
-        const float *p = R1 + (size_t)y1 * W + x1;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1];
-        r4 = (R02 + r4) * 0.5f;
-        r5 = (R03 + r5) * 0.5f;
-        r6 = (R04 + r6) * 0.25f;
+        r2 = a00 * u.g[0][0] + a01 * u.g[1][0] + a10 * u.g[2][0] + a11 * u.g[3][0];
+        r3 = a00 * u.g[0][1] + a01 * u.g[1][1] + a10 * u.g[2][1] + a11 * u.g[3][1];
+        r4 = a00 * u.g[0][2] + a01 * u.g[1][2] + a10 * u.g[2][2] + a11 * u.g[3][2];
+        r5 = a00 * u.g[0][3] + a01 * u.g[1][3] + a10 * u.g[2][3] + a11 * u.g[3][3];
+        r6 = a00 * u.g[0][4] + a01 * u.g[1][4] + a10 * u.g[2][4] + a11 * u.g[3][4];
+        r4 = (u.r0[2] + r4) * 0.5f;
+        r5 = (u.r0[3] + r5) * 0.5f;
+        r6 = (u.r0[4] + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R02; r5 = R03; r6 = R04 * 0.5f;
+        r4 = u.r0[2]; r5 = u.r0[3]; r6 = u.r0[4] * 0.5f;
     }
-    r2 = (R00 - r2) * 0.5f;
-    r3 = (R01 - r3) * 0.5f;
+    r2 = (u.r0[0] - r2) * 0.5f;
+    r3 = (u.r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     constexpr int BORDER = 5;
@@ -405,11 +419,40 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
                       (y < BORDER ? bw(y) : 1.f) * (y >= H - BORDER ? bw(H - y - 1) : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    M[idx] = r4 * r4 + r6 * r6;
-    M[plane + idx] = (r4 + r5) * r6;
-    M[2 * plane + idx] = r5 * r5 + r6 * r6;
-    M[3 * plane + idx] = r4 * r2 + r6 * r3;
-    M[4 * plane + idx] = r6 * r2 + r5 * r3;
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+__device__ __forceinline__ void update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                   size_t plane, int W, int H, int x, int y, float2 fl,
+                                                   float (&m)[5])
+{
+    UmIn u;
+    um_load(R0, R1, plane, W, H, x, y, fl, u);
+    um_math(u, W, H, x, y, fl, m);
+}
+
+__global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R0b,
+                                                         const float *__restrict__ R1b,
+                                                         size_t pair_stride_R,
+                                                         const float *__restrict__ flowb,
+                                                         float *__restrict__ Mb, int W, int H)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)W * H;
+    const float *R0 = R0b + blockIdx.z * pair_stride_R;
+    const float *R1 = R1b + blockIdx.z * pair_stride_R;
+    const float2 fl = reinterpret_cast<const float2 *>(flowb)[(size_t)blockIdx.z * plane + (size_t)y * W + x];
+    float *M = Mb + (size_t)blockIdx.z * 5 * plane;
+    float m[5];
+    update_matrices_px(R0, R1, plane, W, H, x, y, fl, m);
+    const size_t idx = (size_t)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 5; c++) M[c * plane + idx] = m[c];
 }
 
 int launch_update_matrices(const float *R0, const float *R1, size_t pair_stride_R,
@@ -546,6 +589,194 @@ int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int w
         return OFC_EUNSUPPORTED;
     }
 #undef OFC_BOX_CASE
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4+K5 fused: one Farneback iteration  flow_in -> flow_out  without M ever existing in memory.
+// Same column march as k_box_solve, but the incoming row of M is COMPUTED (um_load/um_math: R0, flow_in,
+// bilinear gather of R1) instead of loaded, and the outgoing row comes back from a 16-row ring that lives
+// in REGISTERS (80 VGPRs per lane): the march is unrolled over super-steps of 16 rows so that every ring
+// slot has a compile-time index.  (A first version kept the ring in a work-group-private global buffer:
+// rocprof showed 2.2 GB of WRITE_SIZE and a 50 % L2 miss rate per level-0 launch -- the ring traffic alone
+// was as large as the algorithmic traffic.)
+// HBM traffic per pixel: 20 (R0) + 20 (R1, gathered) + 8 (flow in) + 8 (flow out) = 56 B, versus
+// 68 + 28 (+20 for the second read of M) for the separate kernels.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
+                                                      const float *__restrict__ flow_inb,
+                                                      float *__restrict__ flow_outb, int W, int H,
+                                                      int rows_per_block /* multiple of 16 */)
+{
+    constexpr int TXO = 256 - 2 * M;
+    constexpr int NV = 2 * M + 4;
+    constexpr int NV2 = (NV + 1) / 2;
+    constexpr int PITCH = 256 + 2;
+    __shared__ __align__(16) double vs[5][BS_ROWS][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TXO;
+    const int y_begin = blockIdx.y * rows_per_block;
+    const int y_end = min(y_begin + rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *R0 = Rb + (size_t)blockIdx.z * frame_stride_R;
+    const float *R1 = R0 + frame_stride_R;
+    const float2 *flow_in = reinterpret_cast<const float2 *>(flow_inb) + (size_t)blockIdx.z * plane;
+    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)blockIdx.z * plane;
+    const int xc = min(max(x0 - M + tid, 0), W - 1);
+    const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+
+    float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
+    double v[5] = {0, 0, 0, 0, 0};
+    float last[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- warm-up: rows y_begin-M .. y_begin+M (replicate-clamped), two at a time ----
+#pragma unroll
+    for (int j2 = -M; j2 <= M; j2 += 2) {
+        float2 fl[2];
+        UmIn u[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int row = min(max(y_begin + j2 + q, 0), H - 1);
+            fl[q] = flow_in[(size_t)row * W + xc];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            um_load(R0, R1, plane, W, H, xc, min(max(y_begin + j2 + q, 0), H - 1), fl[q], u[q]);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (j2 + q <= M) {
+                const int row = min(max(y_begin + j2 + q, 0), H - 1);
+                float m[5];
+                um_math(u[q], W, H, xc, row, fl[q], m);
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    ring[(j2 + q + 16) & 15][c] = m[c];
+                    v[c] += (double)m[c];
+                    last[c] = m[c];
+                }
+            }
+        }
+    }
+
+    for (int y16 = y_begin; y16 < y_end; y16 += 16) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int yc = y16 + 4 * q4;
+            if (yc < y_end) {                                   // uniform
+                // ---- advance the window over the 4 rows of this step; loads batched two rows at a time ----
+                float2 fl[BS_ROWS];
+                float mi[BS_ROWS][5];
+#pragma unroll
+                for (int r = 0; r < BS_ROWS; r++)
+                    fl[r] = flow_in[(size_t)min(yc + r + 1 + M, H - 1) * W + xc];
+#pragma unroll
+                for (int r2 = 0; r2 < BS_ROWS; r2 += 2) {
+                    UmIn u[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+                        um_load(R0, R1, plane, W, H, xc, min(yc + r2 + q + 1 + M, H - 1), fl[r2 + q], u[q]);
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int r = r2 + q, e = yc + r + 1 + M;
+                        if (e <= H - 1) {
+                            um_math(u[q], W, H, xc, e, fl[r], mi[r]);
+#pragma unroll
+                            for (int c = 0; c < 5; c++) last[c] = mi[r][c];
+                        } else {                                // replicate the last image row
+#pragma unroll
+                            for (int c = 0; c < 5; c++) mi[r][c] = last[c];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < BS_ROWS; r++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int s_in = (4 * q4 + r + 1 + M) & 15, s_out = (4 * q4 + r + 16 - M) & 15;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        vs[c][r][tid] = v[c];
+                        v[c] += (double)mi[r][c] - (double)ring[s_out][c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 5; c++) ring[s_in][c] = mi[r][c];
+                }
+                __syncthreads();
+                const int y = yc + wave;
+                const int xo = x0 + 4 * lane;
+                if (y < y_end && 4 * lane < TXO && xo < W) {
+                    double S[5][4];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double a[2 * NV2];
+#pragma unroll
+                        for (int q = 0; q < NV2; q++) {
+                            double2 d = *reinterpret_cast<const double2 *>(&vs[c][wave][4 * lane + 2 * q]);
+                            a[2 * q] = d.x; a[2 * q + 1] = d.y;
+                        }
+                        double s = a[0];
+#pragma unroll
+                        for (int q = 1; q <= 2 * M; q++) s += a[q];
+                        S[c][0] = s;
+#pragma unroll
+                        for (int o = 1; o < 4; o++) {
+                            s += a[2 * M + o] - a[o - 1];
+                            S[c][o] = s;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        if (4 * lane + o < TXO && xo + o < W) {
+                            const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                         h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                            flow_out[(size_t)y * W + xo + o] =
+                                make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+int flow_iter_rows(int W, int H, int npair, int winsize)
+{
+    // strips of ~256 rows amortise the 2m-row warm-up; equal-height strips (multiple of 16) avoid a short
+    // last strip, and more strips are cut only when the launch would leave CUs idle
+    const int tiles_x = cdiv(W, 256 - (winsize - 1));
+    int n = std::max(1, (H + 128) / 256);
+    while ((int64_t)tiles_x * n * npair < 512 && cdiv(H, n + 1) >= 32) n++;
+    return cdiv(cdiv(H, n), 16) * 16;
+}
+
+int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
+                     int npair, int W, int H, int winsize, hipStream_t s)
+{
+    if (winsize > 15) { set_error("fused iteration supports winsize <= 15 (ring of 16 rows)"); return OFC_EUNSUPPORTED; }
+    const int rows_per_block = flow_iter_rows(W, H, npair, winsize);
+    dim3 block(256);
+#define OFC_FI_CASE(MM)                                                                              \
+    case 2 * MM + 1: {                                                                               \
+        dim3 grid(cdiv(W, 256 - 2 * MM), cdiv(H, rows_per_block), npair);                            \
+        hipLaunchKernelGGL(k_flow_iter<MM>, grid, block, 0, s, R, frame_stride_R, flow_in, flow_out, \
+                           W, H, rows_per_block);                                                    \
+        break;                                                                                       \
+    }
+    switch (winsize) {
+        OFC_FI_CASE(2)
+        OFC_FI_CASE(3)
+        OFC_FI_CASE(4)
+        OFC_FI_CASE(5)
+        OFC_FI_CASE(6)
+        OFC_FI_CASE(7)
+    default:
+        set_error("winsize %d unsupported by the fused iteration (odd 5..15)", winsize);
+        return OFC_EUNSUPPORTED;
+    }
+#undef OFC_FI_CASE
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

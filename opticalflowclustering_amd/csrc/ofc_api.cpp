@@ -3,7 +3,9 @@
 #include "color_common.h"
 
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 namespace ofc {
@@ -219,7 +221,8 @@ struct ofc_flow {
     PolyConsts pc{};
     std::vector<LevelGeom> geom;    // [0..levels]
     hipStream_t stream = nullptr;
-    DevBuf I, R, M, flowA, flowB;   // scratch sized for level 0 and max_batch
+    DevBuf I, R, M, flowA, flowB, flowC;   // scratch sized for level 0 and max_batch
+    bool fused = true;              // update-matrices fused into the box/solve kernel (winsize <= 15)
     DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
@@ -232,34 +235,44 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
 {
     const int npair = n_frames - 1;
     const int W = f->W, H = f->H;
-    const size_t P0 = (size_t)W * H;
     hipStream_t s = f->stream;
-    float *I = f->I.as<float>(), *R = f->R.as<float>(), *M = f->M.as<float>();
+    float *I = f->I.as<float>(), *R = f->R.as<float>();
+    const int iters = f->prm.iterations;
     float *prevFlow = nullptr;
     int pw = 0, ph = 0;
     for (int k = f->levels; k >= 0; k--) {
         const LevelGeom &g = f->geom[k];
         const size_t P = (size_t)g.w * g.h;
-        // level-k flow lives in flowA/flowB alternately; level 0 goes straight to the caller
-        float *flow = (k == 0) ? flow_dev : (((f->levels - k) & 1) ? f->flowB.as<float>() : f->flowA.as<float>());
+        // the level's final flow lands in `dst` (level 0: the caller's buffer); iterations ping-pong between
+        // dst and tmp, so the initial flow goes to whichever makes the last iteration write dst
+        float *dst = (k == 0) ? flow_dev : (((f->levels - k) & 1) ? f->flowB.as<float>() : f->flowA.as<float>());
+        float *tmp = f->flowC.as<float>();
+        float *cur = f->fused ? ((iters & 1) ? tmp : dst) : dst;
         if (!prevFlow) {
-            OFC_HIP(hipMemsetAsync(flow, 0, sizeof(float) * 2 * P * npair, s));
+            OFC_HIP(hipMemsetAsync(cur, 0, sizeof(float) * 2 * P * npair, s));
         } else {
-            OFC_TRY(launch_flow_resize(prevFlow, flow, npair, pw, ph, g.w, g.h,
-                                       (float)(1. / f->prm.pyr_scale), s));
+            OFC_TRY(launch_flow_resize(prevFlow, cur, npair, pw, ph, g.w, g.h, (float)(1. / f->prm.pyr_scale), s));
         }
         OFC_TRY(launch_level_image(frames_dev, I, n_frames, W, H, g, s));
         OFC_TRY(launch_polyexp(I, R, n_frames, g.w, g.h, f->pc, 0, s));
         const size_t strideR = 5 * P;
-        OFC_TRY(launch_update_matrices(R, R + strideR, strideR, flow, M, npair, g.w, g.h, s));
-        for (int i = 0; i < f->prm.iterations; i++) {
-            OFC_TRY(launch_box_solve(M, flow, npair, g.w, g.h, f->prm.winsize, 0, s));
-            if (i < f->prm.iterations - 1)
-                OFC_TRY(launch_update_matrices(R, R + strideR, strideR, flow, M, npair, g.w, g.h, s));
+        if (f->fused) {
+            for (int i = 0; i < iters; i++) {
+                float *nxt = (cur == dst) ? tmp : dst;
+                OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                cur = nxt;
+            }
+        } else {
+            float *M = f->M.as<float>();
+            OFC_TRY(launch_update_matrices(R, R + strideR, strideR, cur, M, npair, g.w, g.h, s));
+            for (int i = 0; i < iters; i++) {
+                OFC_TRY(launch_box_solve(M, cur, npair, g.w, g.h, f->prm.winsize, 0, s));
+                if (i < iters - 1)
+                    OFC_TRY(launch_update_matrices(R, R + strideR, strideR, cur, M, npair, g.w, g.h, s));
+            }
         }
-        prevFlow = flow;
+        prevFlow = dst;
         pw = g.w; ph = g.h;
-        (void)P0;
     }
     return OFC_OK;
 }
@@ -287,7 +300,15 @@ int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_ba
     const size_t P0 = (size_t)W * H, nb = (size_t)max_batch;
     OFC_TRY(f->I.alloc(sizeof(float) * P0 * (nb + 1)));
     OFC_TRY(f->R.alloc(sizeof(float) * 5 * P0 * (nb + 1)));
-    OFC_TRY(f->M.alloc(sizeof(float) * 5 * P0 * nb));
+    {
+        const char *e = getenv("OFC_FLOW_STAGED");      // debugging aid: force the separate K4 / K5 kernels
+        f->fused = prm.winsize <= 15 && !(e && e[0] == '1');
+    }
+    if (f->fused) {
+        OFC_TRY(f->flowC.alloc(sizeof(float) * 2 * P0 * nb));
+    } else {
+        OFC_TRY(f->M.alloc(sizeof(float) * 5 * P0 * nb));
+    }
     const size_t P1 = f->levels >= 1 ? (size_t)f->geom[1].w * f->geom[1].h : 1;
     OFC_TRY(f->flowA.alloc(sizeof(float) * 2 * P1 * nb));
     OFC_TRY(f->flowB.alloc(sizeof(float) * 2 * P1 * nb));

@@ -97,6 +97,9 @@ int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int w
 // src [npair][sh][sw][2] -> dst [npair][dh][dw][2], * mul
 int launch_flow_resize(const float *src, float *dst, int npair, int sw, int sh, int dw, int dh,
                        float mul, hipStream_t s);
+// fused iteration (update matrices + box mean + solve): R [npair+1][5][H][W]; flow_in != flow_out
+int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
+                     int npair, int W, int H, int winsize, hipStream_t s);
 int polyexp_default_rows(int W, int H, int nimg);
 int box_default_rows(int W, int H, int npair);
 
