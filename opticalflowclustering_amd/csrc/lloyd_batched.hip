@@ -418,7 +418,7 @@ int launch_lloyd_batched(const BatchedArgs &a, int max_points, hipStream_t s)
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
         hipLaunchKernelGGL(k_lloyd_batched<KM>, grid, block, lds, s, a, mp);                           \
     }
-    if (kmax == 4) OFC_LB(4) else if (kmax == 8) OFC_LB(8) else OFC_LB(16)
+    if (kmax <= 4) OFC_LB(4) else if (kmax <= 8) OFC_LB(8) else OFC_LB(16)
 #undef OFC_LB
     OFC_HIP(hipGetLastError());
     return OFC_OK;

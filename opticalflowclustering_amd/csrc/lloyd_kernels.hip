@@ -167,6 +167,11 @@ __device__ __forceinline__ int assign_point(const double (&x)[D], const double *
     return label;
 }
 
+// The M-step partials are NOT kept as k*(d+1) predicated register accumulators (8 x 3 conditional f64 adds per
+// point made the kernel VALU-bound at 2.5 TB/s): every lane owns a private column of LDS accumulators
+// [k*d sums f64][k counts u32] x 256 lanes and adds each point into the slot of its label with one ds_add per
+// component.  A slot is only ever touched by its own lane, in point order, so the sums are deterministic; the
+// 256 columns are folded in a fixed order at the end.  LDS: k*(8d+4)*256 B (25 KB for k=5, d=2).
 template <int D, int KMAX, class T, bool ACCUM>
 __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k,
                                                       const LloydState *__restrict__ st,
@@ -174,7 +179,11 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
                                                       double *__restrict__ partial)
 {
     constexpr int NV = KMAX * D + KMAX + 1;
-    __shared__ double lds[ACCUM ? 4 * NV : 1];
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sacc = reinterpret_cast<double *>(smem);                       // [k*D][256]
+    unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
+    __shared__ unsigned s_changed[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double c[KMAX * D], cn[KMAX], m[D];
 #pragma unroll
     for (int j = 0; j < KMAX; j++) {
@@ -184,12 +193,19 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     }
 #pragma unroll
     for (int f = 0; f < D; f++) m[f] = st->mean[f];
-    double acc[NV];
+    if (ACCUM) {
+        for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
+        for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
+    }
+    unsigned changed = 0;
+    auto accumulate = [&](int l, const double (&x)[D]) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) acc[i] = 0;
+        for (int f = 0; f < D; f++) sacc[(l * D + f) * 256 + tid] += x[f];
+        scnt[l * 256 + tid] += 1u;
+    };
 
     const int64_t n4 = N / 4;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < n4; q += (int64_t)gridDim.x * 256) {
         double x[4][D];
         load4<D>(X, q * 4, x);
         const uchar4 lo = reinterpret_cast<const uchar4 *>(labels)[q];
@@ -200,39 +216,52 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
 #pragma unroll
             for (int f = 0; f < D; f++) x[p][f] -= m[f];
             nl[p] = assign_point<D, KMAX>(x[p], c, cn, k);
-            if (ACCUM) {
+        }
+        if (ACCUM) {
 #pragma unroll
-                for (int j = 0; j < KMAX; j++) {
-                    const bool hit = (nl[p] == j);
-                    acc[KMAX * D + j] += hit ? 1.0 : 0.0;
-#pragma unroll
-                    for (int f = 0; f < D; f++) acc[j * D + f] += hit ? x[p][f] : 0.0;
-                }
-                acc[NV - 1] += (nl[p] != old[p]) ? 1.0 : 0.0;
+            for (int p = 0; p < 4; p++) {
+                accumulate(nl[p], x[p]);
+                changed += (nl[p] != old[p]);
             }
         }
         reinterpret_cast<uchar4 *>(labels)[q] = make_uchar4(nl[0], nl[1], nl[2], nl[3]);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (int)(N - n4 * 4)) {
-        const int64_t i = n4 * 4 + threadIdx.x;
+    if (blockIdx.x == 0 && tid < (int)(N - n4 * 4)) {
+        const int64_t i = n4 * 4 + tid;
         double x[D];
         load1<D>(X, i, x);
 #pragma unroll
         for (int f = 0; f < D; f++) x[f] -= m[f];
         const int l = assign_point<D, KMAX>(x, c, cn, k);
         if (ACCUM) {
-#pragma unroll
-            for (int j = 0; j < KMAX; j++) {
-                const bool hit = (l == j);
-                acc[KMAX * D + j] += hit ? 1.0 : 0.0;
-#pragma unroll
-                for (int f = 0; f < D; f++) acc[j * D + f] += hit ? x[f] : 0.0;
-            }
-            acc[NV - 1] += (l != labels[i]) ? 1.0 : 0.0;
+            accumulate(l, x);
+            changed += (l != labels[i]);
         }
         labels[i] = (uint8_t)l;
     }
-    if (ACCUM) block_reduce_store<NV>(acc, lds, partial + (size_t)blockIdx.x * NV);
+    if (ACCUM) {
+        double *rec = partial + (size_t)blockIdx.x * NV;
+        if (tid < NV) rec[tid] = 0.0;
+        unsigned ch = changed;
+        for (int off = 32; off >= 1; off >>= 1) ch += __shfl_down(ch, off, 64);
+        if (lane == 0) s_changed[wave] = ch;
+        __syncthreads();
+        // fold the 256 private columns: component i by wave i % 4; lanes add their 4 columns in a fixed order,
+        // then a fixed shuffle tree
+        for (int i = wave; i < k * D + k; i += 4) {
+            double a;
+            if (i < k * D) {
+                const double *col = sacc + (size_t)i * 256;
+                a = ((col[lane] + col[lane + 64]) + col[lane + 128]) + col[lane + 192];
+            } else {
+                const unsigned *col = scnt + (size_t)(i - k * D) * 256;
+                a = (double)(col[lane] + col[lane + 64] + col[lane + 128] + col[lane + 192]);
+            }
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) rec[i < k * D ? i : KMAX * D + (i - k * D)] = a;
+        }
+        if (tid == 0) rec[NV - 1] = (double)(s_changed[0] + s_changed[1] + s_changed[2] + s_changed[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -411,18 +440,24 @@ __global__ __launch_bounds__(256) void k_lloyd_farthest(const T *__restrict__ X,
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch over (dtype, D, KMAX)
 // ------------------------------------------------------------------------------------------------
-int lloyd_kmax(int k) { return k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : 0)); }
+// the distance loop is unrolled over a compile-time K: exact for k <= 8, 16 above
+int lloyd_kmax(int k) { return k <= 8 ? k : (k <= 16 ? 16 : 0); }
 
 template <int D, int KMAX, class T>
 static void launch_assign_t(const void *X, int64_t N, int k, const LloydState *st, uint8_t *labels,
                             double *partial, int nblocks, bool accum, hipStream_t s)
 {
-    if (accum)
-        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, true>), dim3(nblocks), dim3(256), 0, s,
+    if (accum) {
+        const size_t lds = (size_t)k * (8 * D + 4) * 256;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd_assign<D, KMAX, T, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, true>), dim3(nblocks), dim3(256), lds, s,
                            (const T *)X, N, k, st, labels, partial);
-    else
+    } else {
         hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, false>), dim3(nblocks), dim3(256), 0, s,
                            (const T *)X, N, k, st, labels, partial);
+    }
 }
 
 template <int D, int KMAX>
@@ -455,9 +490,17 @@ int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const
     if (!kmax) { set_error("k=%d unsupported by the streaming kernel (1..16)", k); return OFC_EUNSUPPORTED; }
     int rc = OFC_OK;
     OFC_D_SWITCH(d, {
-        if (kmax == 4) rc = launch_assign_d<DD, 4>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
-        else if (kmax == 8) rc = launch_assign_d<DD, 8>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
-        else rc = launch_assign_d<DD, 16>(X, dtype, N, k, st, labels, partial, nblocks, accum, s);
+        switch (kmax) {
+        case 1: rc = launch_assign_d<DD, 1>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 2: rc = launch_assign_d<DD, 2>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 3: rc = launch_assign_d<DD, 3>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 4: rc = launch_assign_d<DD, 4>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 5: rc = launch_assign_d<DD, 5>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 6: rc = launch_assign_d<DD, 6>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 7: rc = launch_assign_d<DD, 7>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 8: rc = launch_assign_d<DD, 8>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        default: rc = launch_assign_d<DD, 16>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        }
     })
     return rc;
 }
