@@ -51,7 +51,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                      % (args.gpus, args.gpus))
-    if world > 1:
+    force_dist = os.environ.get("OFC_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch  # noqa: F401  (first: libofc then shares torch's HIP/RCCL runtime instances)
 
     from opticalflowclustering_amd import _lib, dist, stages
@@ -118,7 +119,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pipe, n_iter)
     pipe.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.finalize()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@ def init_rccl(device, rank, world, broadcast_bytes):
 def init_from_torch_env(device):
     """rendezvous through torch.distributed (gloo): returns (rank, world, barrier, allreduce_max)"""
     rank, world, _ = env_rank_world()
-    if world == 1:
+    if world == 1 and os.environ.get("OFC_FORCE_DIST") != "1":      # OFC_FORCE_DIST: rehearse the N>1 path on one GPU
         return 0, 1, (lambda: None), (lambda v: v)
     import torch
     import torch.distributed as td
