@@ -146,6 +146,133 @@ __global__ __launch_bounds__(256) void k_level_image(const uint8_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2 fast paths for the pyramid the reference actually uses (pyr_scale 0.5: exact 1, 2, 4, 8x decimation).
+// Same arithmetic, same order as k_level_image (bit-exact, contraction off); only the data movement differs:
+// window bytes come from aligned dword loads and are unpacked with compile-time shifts (v_cvt_f32_ubyteN),
+// nothing is staged through LDS as bytes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ubyte_of(uint32_t w, int n) { return (float)((w >> (8 * n)) & 255u); }
+
+// level 0: 3x3 blur, no decimation.  Thread = 4 px x 8 rows; block tile 256 x 32.
+__global__ __launch_bounds__(256) void k_level0(const uint8_t *__restrict__ src, float *__restrict__ dst,
+                                                int W, int H, float k0, float k1, float k2)
+{
+#pragma clang fp contract(off)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 256 + 4 * tx, y0 = blockIdx.y * 32 + 8 * ty;
+    if (x0 >= W || y0 >= H) return;
+    const uint8_t *img = src + (size_t)blockIdx.z * W * H;
+    float *out = dst + (size_t)blockIdx.z * W * H;
+    const bool fast = x0 >= 4 && x0 + 8 <= W;         // W % 4 == 0 is guaranteed by the launcher
+    float h[10][4];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        const uint8_t *row = img + (size_t)reflect101(y0 - 1 + j, H) * W;
+        float b[6];
+        if (fast) {
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(row + x0);
+            const uint32_t wa = rw[-1], wb = rw[0], wc = rw[1];
+            b[0] = ubyte_of(wa, 3);
+            b[1] = ubyte_of(wb, 0); b[2] = ubyte_of(wb, 1); b[3] = ubyte_of(wb, 2); b[4] = ubyte_of(wb, 3);
+            b[5] = ubyte_of(wc, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) b[q] = (float)row[reflect101(x0 - 1 + q, W)];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float acc = k0 * b[c];
+            acc += k1 * b[c + 1];
+            acc += k2 * b[c + 2];
+            h[j][c] = acc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (y0 + i < H) {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float d = k1 * h[i + 1][c];
+                d += k2 * (h[i][c] + h[i + 2][c]);
+                o[c] = d;
+            }
+            *reinterpret_cast<float4 *>(out + (size_t)(y0 + i) * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// exact S-fold decimation with a (2R+1)-tap Gaussian.  Row pass: one item = (input row, output column):
+// both bilinear x taps (xa, xa+1) from ONE 2R+2 byte window held in registers.  Column pass: both y taps from one
+// 2R+2 row window of the row-filtered samples in LDS.
+template <int S, int R, int TXO, int TYO>
+__global__ __launch_bounds__(256) void k_level_dec(const uint8_t *__restrict__ src, float *__restrict__ dst,
+                                                   int W0, int H0, int w, int h, LevelArgs p)
+{
+#pragma clang fp contract(off)
+    constexpr int ROWS = S * TYO + 2 * R;                 // input rows feeding the tile
+    constexpr int NB = 2 * R + 2;                         // bytes per window
+    constexpr int XOFF = (S / 2 - 1 - R);                 // window start relative to S*ox
+    constexpr int AL = ((XOFF % 4) + 4) % 4;              // its offset inside the first aligned dword
+    constexpr int NW = (AL + NB + 3) / 4;                 // aligned dwords covering the window
+    __shared__ float hrow[ROWS][TXO][2];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * TXO, oy0 = blockIdx.y * TYO;
+    const uint8_t *img = src + (size_t)blockIdx.z * W0 * H0;
+    float *out = dst + (size_t)blockIdx.z * w * h;
+    const int yfirst = S * oy0 + S / 2 - 1 - R;           // global row of tile row 0 (before reflection)
+
+    for (int it = tid; it < ROWS * TXO; it += 256) {
+        const int ly = it / TXO, j = it - ly * TXO;
+        const int ox = ox0 + j;
+        if (ox >= w) continue;
+        const uint8_t *row = img + (size_t)reflect101(yfirst + ly, H0) * W0;
+        const int xs = S * ox + XOFF;                     // first byte of the window
+        float b[NB];
+        if (xs - AL >= 0 && xs - AL + 4 * NW <= W0) {
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(row + (xs - AL));
+            uint32_t wd[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) wd[q] = rw[q];
+#pragma unroll
+            for (int q = 0; q < NB; q++) b[q] = ubyte_of(wd[(AL + q) >> 2], (AL + q) & 3);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; q++) b[q] = (float)row[reflect101(xs + q, W0)];
+        }
+        float a0 = p.kern[0] * b[0], a1 = p.kern[0] * b[1];
+#pragma unroll
+        for (int q = 1; q <= 2 * R; q++) {
+            a0 += p.kern[q] * b[q];
+            a1 += p.kern[q] * b[q + 1];
+        }
+        hrow[ly][j][0] = a0;
+        hrow[ly][j][1] = a1;
+    }
+    __syncthreads();
+    for (int it = tid; it < TYO * TXO; it += 256) {
+        const int oy = it / TXO, j = it - oy * TXO;
+        if (ox0 + j >= w || oy0 + oy >= h) continue;
+        const int c0 = S * oy + R;                        // tile row of the first y tap's centre
+        float2 win[2 * R + 2];
+#pragma unroll
+        for (int q = 0; q < 2 * R + 2; q++) win[q] = *reinterpret_cast<const float2 *>(&hrow[c0 - R + q][j][0]);
+        float hy[2];
+#pragma unroll
+        for (int yt = 0; yt < 2; yt++) {
+            float v0 = p.kern[R] * win[R + yt].x, v1 = p.kern[R] * win[R + yt].y;
+#pragma unroll
+            for (int m = 1; m <= R; m++) {
+                v0 += p.kern[R + m] * (win[R + yt - m].x + win[R + yt + m].x);
+                v1 += p.kern[R + m] * (win[R + yt - m].y + win[R + yt + m].y);
+            }
+            hy[yt] = v0 * 0.5f + v1 * 0.5f;
+        }
+        out[(size_t)(oy0 + oy) * w + ox0 + j] = hy[0] * 0.5f + hy[1] * 0.5f;
+    }
+}
+
 int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
                        const LevelGeom &g, hipStream_t s)
 {
@@ -156,7 +283,26 @@ int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
     if (g.ksize > 31) { set_error("blur kernel size %d > 31 unsupported", g.ksize); return OFC_EUNSUPPORTED; }
     gaussian_kernel(g.ksize, g.sigma, a.kern);
     a.sx = (double)W0 / g.w; a.sy = (double)H0 / g.h;
-    // output tile: big for the fine levels, small for the coarse ones (input footprint ~ scale)
+    // fast paths: exact decimation by 1 / 2 / 4 / 8 with the reference's tap counts, rows dword-addressable
+    const bool aligned = (W0 % 4) == 0 && ((uintptr_t)src % 4) == 0 && (((size_t)W0 * H0) % 4) == 0;
+    if (aligned && g.w == W0 && g.h == H0 && a.r == 1) {
+        hipLaunchKernelGGL(k_level0, dim3(cdiv(W0, 256), cdiv(H0, 32), nimg), dim3(256), 0, s, src, dst, W0, H0,
+                           a.kern[0], a.kern[1], a.kern[2]);
+        OFC_HIP(hipGetLastError());
+        return OFC_OK;
+    }
+#define OFC_DEC(S_, R_, TX_, TY_)                                                                          \
+    if (aligned && g.w * S_ == W0 && g.h * S_ == H0 && a.r == R_) {                                        \
+        hipLaunchKernelGGL((k_level_dec<S_, R_, TX_, TY_>), dim3(cdiv(g.w, TX_), cdiv(g.h, TY_), nimg),    \
+                           dim3(256), 0, s, src, dst, W0, H0, g.w, g.h, a);                                \
+        OFC_HIP(hipGetLastError());                                                                        \
+        return OFC_OK;                                                                                     \
+    }
+    OFC_DEC(2, 1, 64, 16)
+    OFC_DEC(4, 4, 32, 8)
+    OFC_DEC(8, 9, 32, 8)
+#undef OFC_DEC
+    // general path (any scale / tap count): LDS-staged tile
     if (a.sx <= 2.5) { a.txo = 64; a.tyo = 16; } else { a.txo = 32; a.tyo = 8; }
     a.in_w = (int)(a.txo * a.sx) + 2 * a.r + 4;
     a.in_h = (int)(a.tyo * a.sy) + 2 * a.r + 4;
