@@ -739,6 +739,36 @@ int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int w
     return OFC_OK;
 }
 
+// one vector of resize(prevFlow, (w,h), INTER_LINEAR) * mul at (x, y): the arithmetic of k_flow_resize (bit-exact)
+struct UpsArgs {
+    const float *src;     // coarse flow [pair][sh][sw][2]; nullptr = flow_in is already at this level's size
+    int sw, sh;
+    double scx, scy;
+    float mul;
+};
+
+__device__ __forceinline__ float2 upsampled_flow(const float2 *__restrict__ s, int sw, int sh, double scx, double scy,
+                                                 float mul, int x, int y)
+{
+#pragma clang fp contract(off)
+    int sx0, sy0, sy1;
+    float a1, b1;
+    lin_tap_x(x, scx, sw, sx0, a1);
+    lin_tap_y(y, scy, sh, sy0, sy1, b1);
+    const float a0 = 1.f - a1, b0 = 1.f - b1;
+    const int sx1 = (a1 == 0.f) ? sx0 : sx0 + 1;
+    const float2 p00 = s[(size_t)sy0 * sw + sx0], p01 = s[(size_t)sy0 * sw + sx1];
+    const float2 p10 = s[(size_t)sy1 * sw + sx0], p11 = s[(size_t)sy1 * sw + sx1];
+    float h0x, h0y, h1x, h1y;
+    if (a1 == 0.f) {
+        h0x = p00.x; h0y = p00.y; h1x = p10.x; h1y = p10.y;
+    } else {
+        h0x = p00.x * a0 + p01.x * a1; h0y = p00.y * a0 + p01.y * a1;
+        h1x = p10.x * a0 + p11.x * a1; h1y = p10.y * a0 + p11.y * a1;
+    }
+    return make_float2((h0x * b0 + h1x * b1) * mul, (h0y * b0 + h1y * b1) * mul);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4+K5 fused: one Farneback iteration  flow_in -> flow_out  without M ever existing in memory.
 // Same column march as k_box_solve, but the incoming row of M is COMPUTED (um_load/um_math: R0, flow_in,
@@ -750,11 +780,13 @@ int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int w
 // HBM traffic per pixel: 20 (R0) + 20 (R1, gathered) + 8 (flow in) + 8 (flow out) = 56 B, versus
 // 68 + 28 (+20 for the second read of M) for the separate kernels.
 // ------------------------------------------------------------------------------------------------
-template <int M>
+// UPS: the first iteration of a level reads its initial flow straight from the coarser level (bilinear x2, times
+// 1/pyr_scale) instead of from a materialised upsampled copy -- K6 fused in, 16 B/px less traffic and one launch less.
+template <int M, bool UPS>
 __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
                                                       const float *__restrict__ flow_inb,
                                                       float *__restrict__ flow_outb, int W, int H,
-                                                      int rows_per_block /* multiple of 16 */)
+                                                      int rows_per_block /* multiple of 16 */, UpsArgs ups)
 {
     constexpr int TXO = 256 - 2 * M;
     constexpr int NV = 2 * M + 4;
@@ -768,10 +800,15 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     const size_t plane = (size_t)W * H;
     const float *R0 = Rb + (size_t)blockIdx.z * frame_stride_R;
     const float *R1 = R0 + frame_stride_R;
-    const float2 *flow_in = reinterpret_cast<const float2 *>(flow_inb) + (size_t)blockIdx.z * plane;
+    const float2 *flow_in = UPS ? reinterpret_cast<const float2 *>(ups.src) + (size_t)blockIdx.z * ups.sw * ups.sh
+                                : reinterpret_cast<const float2 *>(flow_inb) + (size_t)blockIdx.z * plane;
     float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)blockIdx.z * plane;
     const int xc = min(max(x0 - M + tid, 0), W - 1);
     const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+    auto flow_at = [&](int row) -> float2 {
+        if (UPS) return upsampled_flow(flow_in, ups.sw, ups.sh, ups.scx, ups.scy, ups.mul, xc, row);
+        return flow_in[(size_t)row * W + xc];
+    };
 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
@@ -785,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int row = min(max(y_begin + j2 + q, 0), H - 1);
-            fl[q] = flow_in[(size_t)row * W + xc];
+            fl[q] = flow_at(row);
         }
 #pragma unroll
         for (int q = 0; q < 2; q++)
@@ -816,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                 float mi[BS_ROWS][5];
 #pragma unroll
                 for (int r = 0; r < BS_ROWS; r++)
-                    fl[r] = flow_in[(size_t)min(yc + r + 1 + M, H - 1) * W + xc];
+                    fl[r] = flow_at(min(yc + r + 1 + M, H - 1));
 #pragma unroll
                 for (int r2 = 0; r2 < BS_ROWS; r2 += 2) {
                     UmIn u[2];
@@ -899,17 +936,25 @@ int flow_iter_rows(int W, int H, int npair, int winsize)
 }
 
 int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
-                     int npair, int W, int H, int winsize, hipStream_t s)
+                     int npair, int W, int H, int winsize, hipStream_t s, const float *coarse, int sw, int sh,
+                     float mul)
 {
     if (winsize > 15) { set_error("fused iteration supports winsize <= 15 (ring of 16 rows)"); return OFC_EUNSUPPORTED; }
     const int rows_per_block = flow_iter_rows(W, H, npair, winsize);
+    UpsArgs u;
+    u.src = coarse; u.sw = sw; u.sh = sh; u.mul = mul;
+    u.scx = coarse ? (double)sw / W : 1.0; u.scy = coarse ? (double)sh / H : 1.0;
     dim3 block(256);
-#define OFC_FI_CASE(MM)                                                                              \
-    case 2 * MM + 1: {                                                                               \
-        dim3 grid(cdiv(W, 256 - 2 * MM), cdiv(H, rows_per_block), npair);                            \
-        hipLaunchKernelGGL(k_flow_iter<MM>, grid, block, 0, s, R, frame_stride_R, flow_in, flow_out, \
-                           W, H, rows_per_block);                                                    \
-        break;                                                                                       \
+#define OFC_FI_CASE(MM)                                                                                  \
+    case 2 * MM + 1: {                                                                                   \
+        dim3 grid(cdiv(W, 256 - 2 * MM), cdiv(H, rows_per_block), npair);                                \
+        if (coarse)                                                                                      \
+            hipLaunchKernelGGL((k_flow_iter<MM, true>), grid, block, 0, s, R, frame_stride_R, flow_in,   \
+                               flow_out, W, H, rows_per_block, u);                                       \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_flow_iter<MM, false>), grid, block, 0, s, R, frame_stride_R, flow_in,  \
+                               flow_out, W, H, rows_per_block, u);                                       \
+        break;                                                                                           \
     }
     switch (winsize) {
         OFC_FI_CASE(2)

@@ -247,22 +247,35 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
         // dst and tmp, so the initial flow goes to whichever makes the last iteration write dst
         float *dst = (k == 0) ? flow_dev : (((f->levels - k) & 1) ? f->flowB.as<float>() : f->flowA.as<float>());
         float *tmp = f->flowC.as<float>();
-        float *cur = f->fused ? ((iters & 1) ? tmp : dst) : dst;
-        if (!prevFlow) {
-            OFC_HIP(hipMemsetAsync(cur, 0, sizeof(float) * 2 * P * npair, s));
-        } else {
-            OFC_TRY(launch_flow_resize(prevFlow, cur, npair, pw, ph, g.w, g.h, (float)(1. / f->prm.pyr_scale), s));
-        }
         OFC_TRY(launch_level_image(frames_dev, I, n_frames, W, H, g, s));
         OFC_TRY(launch_polyexp(I, R, n_frames, g.w, g.h, f->pc, 0, s));
         const size_t strideR = 5 * P;
+        const float mul = (float)(1. / f->prm.pyr_scale);
         if (f->fused) {
+            // iteration i writes dst when (iters-1-i) is even, tmp otherwise; the first one reads the coarser
+            // level directly (upsample fused) or, at the top of the pyramid, a zeroed buffer
+            const float *cur = nullptr;
             for (int i = 0; i < iters; i++) {
-                float *nxt = (cur == dst) ? tmp : dst;
-                OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                float *nxt = ((iters - 1 - i) & 1) ? tmp : dst;
+                if (i == 0 && prevFlow) {
+                    OFC_TRY(launch_flow_iter(R, strideR, nullptr, nxt, npair, g.w, g.h, f->prm.winsize, s, prevFlow, pw, ph, mul));
+                } else {
+                    if (i == 0) {
+                        float *z = (nxt == dst) ? tmp : dst;
+                        OFC_HIP(hipMemsetAsync(z, 0, sizeof(float) * 2 * P * npair, s));
+                        cur = z;
+                    }
+                    OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                }
                 cur = nxt;
             }
         } else {
+            float *cur = dst;
+            if (!prevFlow) {
+                OFC_HIP(hipMemsetAsync(cur, 0, sizeof(float) * 2 * P * npair, s));
+            } else {
+                OFC_TRY(launch_flow_resize(prevFlow, cur, npair, pw, ph, g.w, g.h, mul, s));
+            }
             float *M = f->M.as<float>();
             OFC_TRY(launch_update_matrices(R, R + strideR, strideR, cur, M, npair, g.w, g.h, s));
             for (int i = 0; i < iters; i++) {

@@ -98,8 +98,10 @@ int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int w
 int launch_flow_resize(const float *src, float *dst, int npair, int sw, int sh, int dw, int dh,
                        float mul, hipStream_t s);
 // fused iteration (update matrices + box mean + solve): R [npair+1][5][H][W]; flow_in != flow_out
+// coarse != nullptr: the initial flow is resize(coarse [npair][sh][sw][2], (W,H)) * mul, sampled on the fly
 int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
-                     int npair, int W, int H, int winsize, hipStream_t s);
+                     int npair, int W, int H, int winsize, hipStream_t s, const float *coarse = nullptr,
+                     int sw = 0, int sh = 0, float mul = 1.f);
 int polyexp_default_rows(int W, int H, int nimg);
 int box_default_rows(int W, int H, int npair);
 
