@@ -13,6 +13,7 @@
 #include "ofc_common.h"
 
 #include <algorithm>
+#include <climits>
 
 namespace ofc {
 
@@ -927,12 +928,20 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 
 int flow_iter_rows(int W, int H, int npair, int winsize)
 {
-    // strips of ~256 rows amortise the 2m-row warm-up; equal-height strips (multiple of 16) avoid a short
-    // last strip, and more strips are cut only when the launch would leave CUs idle
+    // cost model: a launch runs in ceil(blocks / resident) rounds (224 VGPRs -> 2 work-groups per CU), each as
+    // long as one strip incl. its 2m-row window warm-up.  Pick the strip count that minimises rounds x strip.
     const int tiles_x = cdiv(W, 256 - (winsize - 1));
-    int n = std::max(1, (H + 128) / 256);
-    while ((int64_t)tiles_x * n * npair < 512 && cdiv(H, n + 1) >= 32) n++;
-    return cdiv(cdiv(H, n), 16) * 16;
+    const int resident = 2 * 256;
+    int best_rows = cdiv(H, 16) * 16;
+    int64_t best_cost = LLONG_MAX;
+    for (int n = 1; n <= 32; n++) {
+        const int rows = cdiv(cdiv(H, n), 16) * 16;
+        if (rows < 32 && n > 1) break;
+        const int64_t blocks = (int64_t)tiles_x * cdiv(H, rows) * npair;
+        const int64_t cost = cdiv64(blocks, resident) * (rows + winsize - 1);
+        if (cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    return best_rows;
 }
 
 int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,

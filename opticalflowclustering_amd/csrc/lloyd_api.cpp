@@ -27,17 +27,36 @@ static double np_sum_small(const double *a, int n)
 
 static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC_F32 ? 4 : 8); }
 
+// Per-device scratch, created once and reused by every fit: creating/destroying a HIP stream (1.5-6 ms) and
+// pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
     DevBuf state, partial, tot, excl, far, labels;
     LloydStatus *status = nullptr;       // pinned, device-visible
     LloydStatus *status_dev = nullptr;
     hipStream_t stream = nullptr;
-    ~LloydScratch()
+    bool ready = false;
+    int init()
     {
-        if (status) (void)hipHostFree(status);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (ready) return OFC_OK;
+        constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1;
+        OFC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        OFC_TRY(state.alloc(sizeof(LloydState)));
+        OFC_TRY(partial.alloc(sizeof(double) * 2048 * NVMAX));
+        OFC_TRY(tot.alloc(sizeof(double) * (NVMAX + 8)));
+        OFC_TRY(excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
+        OFC_TRY(far.alloc(sizeof(double) * 2 * 2048));
+        OFC_HIP(hipHostMalloc((void **)&status, sizeof(LloydStatus), hipHostMallocMapped));
+        OFC_HIP(hipHostGetDevicePointer((void **)&status_dev, status, 0));
+        ready = true;
+        return OFC_OK;
     }
 };
+
+static LloydScratch &scratch_for(int device)
+{
+    static LloydScratch *pool = new LloydScratch[16];   // intentionally never destroyed (no HIP calls at exit)
+    return pool[device & 15];
+}
 
 // empty-cluster relocation (_k_means_common.pyx:167-211) on the all-reduced totals `tot`.
 // Returns with `tot` patched on the device (or untouched when the farthest distance is 0).
@@ -141,19 +160,12 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     OFC_TRY(ensure_device(device));
     const int kmax = lloyd_kmax(k);
     const int NV = kmax * d + kmax + 1;
-    LloydScratch sc;
-    OFC_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+    LloydScratch &sc = scratch_for(device);
+    OFC_TRY(sc.init());
     hipStream_t s = sc.stream;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
-    OFC_TRY(sc.state.alloc(sizeof(LloydState)));
-    OFC_TRY(sc.partial.alloc(sizeof(double) * (size_t)nblocks * NV));
-    OFC_TRY(sc.tot.alloc(sizeof(double) * (NV + 8)));
-    OFC_TRY(sc.excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
-    OFC_TRY(sc.far.alloc(sizeof(double) * std::max(2 * nblocks, 16)));
-    OFC_HIP(hipHostMalloc((void **)&sc.status, sizeof(LloydStatus), hipHostMallocMapped));
-    OFC_HIP(hipHostGetDevicePointer((void **)&sc.status_dev, sc.status, 0));
     if (!labels_dev) {
-        OFC_TRY(sc.labels.alloc((size_t)std::max<int64_t>(N, 1)));
+        if (sc.labels.bytes < (size_t)std::max<int64_t>(N, 1)) OFC_TRY(sc.labels.alloc((size_t)std::max<int64_t>(N, 1)));
         labels_dev = sc.labels.as<uint8_t>();
     }
     LloydState *st = sc.state.as<LloydState>();
