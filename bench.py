@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="frame pairs per flow launch sequence")
     ap.add_argument("--frames", type=int, default=CLIP_FRAMES, help="clip length (default = the named config)")
+    ap.add_argument("--engines", type=int, default=2, help="flow engines (HIP streams) fed round-robin")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -64,7 +65,7 @@ def main():
 
     n_pairs_total = args.frames - 1
     p0, p1 = shard_pairs(n_pairs_total, world, rank)
-    pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=args.batch, device=device)
+    pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=args.batch, device=device, n_engines=args.engines)
     pipe.synth(t0=p0, seed=0)
 
     def step():
@@ -125,7 +126,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(pipe, n_iter, sample_pairs=4):
+def cpu_baseline(pipe, n_iter, sample_pairs=16):
     """the CPU restatement of the same path (oracle/, C, single thread) on the first `sample_pairs`
     pairs of the clip: Farneback per pair, then Lloyd (same init, to convergence) over their (u,v)"""
     from oracle import oracle as O

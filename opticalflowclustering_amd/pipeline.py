@@ -21,12 +21,16 @@ def shard_pairs(n_pairs, world, rank):
 
 
 class ClipPipeline:
-    def __init__(self, W, H, n_frames_local, batch_pairs=16, params=None, device=0):
+    def __init__(self, W, H, n_frames_local, batch_pairs=16, params=None, device=0, n_engines=2):
         self.W, self.H, self.device = W, H, device
         self.n_frames = int(n_frames_local)
         self.n_pairs = self.n_frames - 1
         self.batch = max(1, min(int(batch_pairs), self.n_pairs))
-        self.engine = FlowEngine(W, H, params or FbParams(), max_batch=self.batch, device=device)
+        # two engines = two HIP streams: consecutive batches are independent, so their kernels overlap and fill
+        # each other's tails / latency-bound phases
+        self.engines = [FlowEngine(W, H, params or FbParams(), max_batch=self.batch, device=device)
+                        for _ in range(max(1, min(n_engines, -(-self.n_pairs // self.batch))))]
+        self.engine = self.engines[0]
         P = W * H
         self.frames = DeviceBuffer(self.n_frames * P, device)
         self.flows = DeviceBuffer(self.n_pairs * P * 8, device)
@@ -44,16 +48,21 @@ class ClipPipeline:
 
     def run_flow(self, sync=True):
         P = self.W * self.H
-        for p0 in range(0, self.n_pairs, self.batch):
+        for i, p0 in enumerate(range(0, self.n_pairs, self.batch)):
             n = min(self.batch, self.n_pairs - p0)
-            self.engine.calc_frames_dev(self.frames.ptr + p0 * P, n + 1, self.flows.ptr + p0 * P * 8, sync=False)
+            self.engines[i % len(self.engines)].calc_frames_dev(self.frames.ptr + p0 * P, n + 1,
+                                                                self.flows.ptr + p0 * P * 8, sync=False)
         if sync:
-            self.engine.sync()
+            self.sync()
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
 
     def run_kmeans(self, init, max_iter=300, tol=1e-4):
         """Lloyd over all local (u,v) vectors (global when a communicator is active).
         -> centers (k,2), inertia, n_iter"""
-        self.engine.sync()
+        self.sync()
         N = self.n_pairs * self.W * self.H
         return kmeans_fit_dev(self.flows.ptr, _lib.F32, N, 2, init, max_iter, tol, self.labels.ptr, self.device)
 
@@ -71,6 +80,7 @@ class ClipPipeline:
         return self.labels.download((self.n_pairs, self.H, self.W), np.uint8)
 
     def close(self):
-        self.engine.close()
+        for e in self.engines:
+            e.close()
         for b in (self.frames, self.flows, self.labels):
             b.free()
