@@ -448,11 +448,12 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
                 }
                 float *o0 = out + (size_t)y * W + xo;
                 if (vec_ok) {   // W % 4 == 0 -> xo+3 < W and 16-B aligned
-                    *reinterpret_cast<float4 *>(o0) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-                    *reinterpret_cast<float4 *>(o0 + plane) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-                    *reinterpret_cast<float4 *>(o0 + 2 * plane) = make_float4(r2[0], r2[1], r2[2], r2[3]);
-                    *reinterpret_cast<float4 *>(o0 + 3 * plane) = make_float4(r3[0], r3[1], r3[2], r3[3]);
-                    *reinterpret_cast<float4 *>(o0 + 4 * plane) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((v4f){r0[0], r0[1], r0[2], r0[3]}, reinterpret_cast<v4f *>(o0));
+                    __builtin_nontemporal_store((v4f){r1[0], r1[1], r1[2], r1[3]}, reinterpret_cast<v4f *>(o0 + plane));
+                    __builtin_nontemporal_store((v4f){r2[0], r2[1], r2[2], r2[3]}, reinterpret_cast<v4f *>(o0 + 2 * plane));
+                    __builtin_nontemporal_store((v4f){r3[0], r3[1], r3[2], r3[3]}, reinterpret_cast<v4f *>(o0 + 3 * plane));
+                    __builtin_nontemporal_store((v4f){r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<v4f *>(o0 + 4 * plane));
                 } else {
 #pragma unroll
                     for (int o = 0; o < 4; o++)

@@ -36,8 +36,10 @@ template <int D>
 __device__ __forceinline__ void load4(const float *X, int64_t i, double (&x)[4][D])
 {
     if constexpr (D == 2) {
-        const float4 a = *reinterpret_cast<const float4 *>(X + i * 2);
-        const float4 b = *reinterpret_cast<const float4 *>(X + i * 2 + 4);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        // streamed once per iteration and far larger than any cache: non-temporal
+        const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(X + i * 2));
+        const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(X + i * 2 + 4));
         x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
         x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
     } else if constexpr (D == 4) {
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < n4; q += (int64_t)gridDim.x * 256) {
         double x[4][D];
         load4<D>(X, q * 4, x);
-        const uchar4 lo = reinterpret_cast<const uchar4 *>(labels)[q];
-        const int old[4] = {lo.x, lo.y, lo.z, lo.w};
+        const unsigned lo = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q);
+        const int old[4] = {(int)(lo & 255u), (int)((lo >> 8) & 255u), (int)((lo >> 16) & 255u), (int)(lo >> 24)};
         int nl[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
                 changed += (nl[p] != old[p]);
             }
         }
-        reinterpret_cast<uchar4 *>(labels)[q] = make_uchar4(nl[0], nl[1], nl[2], nl[3]);
+        __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)), reinterpret_cast<unsigned *>(labels) + q);
     }
     if (blockIdx.x == 0 && tid < (int)(N - n4 * 4)) {
         const int64_t i = n4 * 4 + tid;
