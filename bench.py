@@ -113,7 +113,7 @@ def main():
         ms = stages.bench_polyexp(W, H, n_img, iters, 0, device)
         achieved = POLYEXP_BYTES_PER_PX * W * H * n_img / (ms * 1e-3) / 1e9
         out["roofline"] = {"kernel": "k_polyexp", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                            "launch_ms": ms, "images_per_launch": n_img,
                            "algorithmic_bytes_per_launch": POLYEXP_BYTES_PER_PX * W * H * n_img}
         # ---- CPU baseline: the oracle (1 thread) on a bounded sample of the same clip ----
@@ -124,6 +124,17 @@ def main():
         dist.finalize()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_polyexp_pmc.json:
+    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot be read from inside
+    the benchmark process, so this is the recorded value for the same launch configuration, or null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_polyexp_pmc.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(pipe, n_iter, sample_pairs=16):
