@@ -788,7 +788,8 @@ template <int M, bool UPS>
 __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
                                                       const float *__restrict__ flow_inb,
                                                       float *__restrict__ flow_outb, int W, int H,
-                                                      int rows_per_block /* multiple of 16 */, UpsArgs ups)
+                                                      int rows_per_block /* multiple of 16 */, UpsArgs ups,
+                                                      int tiles_x, int n_strips, int npair)
 {
     constexpr int TXO = 256 - 2 * M;
     constexpr int NV = 2 * M + 4;
@@ -796,15 +797,24 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     constexpr int PITCH = 256 + 2;
     __shared__ __align__(16) double vs[5][BS_ROWS][PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * TXO;
-    const int y_begin = blockIdx.y * rows_per_block;
+    // XCD-aware work-group -> (tile, pair) map.  Work-groups are dealt round-robin over the 8 XCDs, so ids L and
+    // L+8 share an L2.  Consecutive same-XCD ids take the SAME tile of CONSECUTIVE pairs: frame t's R is R1 of pair
+    // t-1 and R0 of pair t, and the two work-groups march down their strips in step, so the second read hits L2
+    // instead of HBM.  (speed only: any placement gives the same result)
+    const int tiles = tiles_x * n_strips;
+    const int group = blockIdx.x / (8 * npair), rem = blockIdx.x - group * (8 * npair);
+    const int pair = rem >> 3, tile = group * 8 + (rem & 7);
+    if (tile >= tiles) return;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * TXO;
+    const int y_begin = tile_y * rows_per_block;
     const int y_end = min(y_begin + rows_per_block, H);
     const size_t plane = (size_t)W * H;
-    const float *R0 = Rb + (size_t)blockIdx.z * frame_stride_R;
+    const float *R0 = Rb + (size_t)pair * frame_stride_R;
     const float *R1 = R0 + frame_stride_R;
-    const float2 *flow_in = UPS ? reinterpret_cast<const float2 *>(ups.src) + (size_t)blockIdx.z * ups.sw * ups.sh
-                                : reinterpret_cast<const float2 *>(flow_inb) + (size_t)blockIdx.z * plane;
-    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)blockIdx.z * plane;
+    const float2 *flow_in = UPS ? reinterpret_cast<const float2 *>(ups.src) + (size_t)pair * ups.sw * ups.sh
+                                : reinterpret_cast<const float2 *>(flow_inb) + (size_t)pair * plane;
+    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)pair * plane;
     const int xc = min(max(x0 - M + tid, 0), W - 1);
     const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
     auto flow_at = [&](int row) -> float2 {
@@ -856,17 +866,16 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
                 for (int r = 0; r < BS_ROWS; r++)
                     fl[r] = flow_at(min(yc + r + 1 + M, H - 1));
+                {
+                    UmIn u[BS_ROWS];
 #pragma unroll
-                for (int r2 = 0; r2 < BS_ROWS; r2 += 2) {
-                    UmIn u[2];
+                    for (int q = 0; q < BS_ROWS; q++)            // the gathers of all four rows in flight together
+                        um_load(R0, R1, plane, W, H, xc, min(yc + q + 1 + M, H - 1), fl[q], u[q]);
 #pragma unroll
-                    for (int q = 0; q < 2; q++)
-                        um_load(R0, R1, plane, W, H, xc, min(yc + r2 + q + 1 + M, H - 1), fl[r2 + q], u[q]);
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int r = r2 + q, e = yc + r + 1 + M;
+                    for (int r = 0; r < BS_ROWS; r++) {
+                        const int e = yc + r + 1 + M;
                         if (e <= H - 1) {
-                            um_math(u[q], W, H, xc, e, fl[r], mi[r]);
+                            um_math(u[r], W, H, xc, e, fl[r], mi[r]);
 #pragma unroll
                             for (int c = 0; c < 5; c++) last[c] = mi[r][c];
                         } else {                                // replicate the last image row
@@ -957,13 +966,14 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
     dim3 block(256);
 #define OFC_FI_CASE(MM)                                                                                  \
     case 2 * MM + 1: {                                                                                   \
-        dim3 grid(cdiv(W, 256 - 2 * MM), cdiv(H, rows_per_block), npair);                                \
+        const int tx = cdiv(W, 256 - 2 * MM), ns = cdiv(H, rows_per_block);                              \
+        dim3 grid(cdiv(tx * ns, 8) * 8 * npair);                                                         \
         if (coarse)                                                                                      \
             hipLaunchKernelGGL((k_flow_iter<MM, true>), grid, block, 0, s, R, frame_stride_R, flow_in,   \
-                               flow_out, W, H, rows_per_block, u);                                       \
+                               flow_out, W, H, rows_per_block, u, tx, ns, npair);                        \
         else                                                                                             \
             hipLaunchKernelGGL((k_flow_iter<MM, false>), grid, block, 0, s, R, frame_stride_R, flow_in,  \
-                               flow_out, W, H, rows_per_block, u);                                       \
+                               flow_out, W, H, rows_per_block, u, tx, ns, npair);                        \
         break;                                                                                           \
     }
     switch (winsize) {
