@@ -886,9 +886,11 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         }
                     }
                 }
+                // the barrier that protects `vs` from the previous step's readers sits HERE, after this step's loads and
+                // matrix arithmetic: a wave that finished its horizontal pass early starts its gathers without waiting
+                __syncthreads();
 #pragma unroll
                 for (int r = 0; r < BS_ROWS; r++) {
-                    constexpr int dummy = 0; (void)dummy;
                     const int s_in = (4 * q4 + r + 1 + M) & 15, s_out = (4 * q4 + r + 16 - M) & 15;
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
@@ -932,7 +934,6 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         }
                     }
                 }
-                __syncthreads();
             }
         }
     }
