@@ -149,3 +149,24 @@ def test_bad_arguments_raise():
     with pytest.raises(ValueError):
         eng.calc(np.zeros((32, 32), np.uint8), np.zeros((32, 32), np.uint8))
     eng.close()
+
+
+def test_flow_4k_pair_and_grid_cells():
+    """BASELINE.json configs[4] shape: 3840x2160 frames, 14x25 grid (153x154 cells = 23 562 points, the largest
+    problem of the LDS-resident batched k-means)"""
+    from opticalflowclustering_amd.flow import FlowEngine
+    from opticalflowclustering_amd.vis import flow_to_bgr, grid_kmeans
+    W, H = 3840, 2160
+    a, b = synth.translated_pair(W, H, 2.5, -1.25)
+    eng = FlowEngine(W, H)
+    got = eng.calc(a, b)
+    eng.close()
+    want = O.farneback(a, b)
+    assert rel(got, want) <= 1e-4 and np.abs(got - want).max() <= 1e-3
+    bgr, _ = flow_to_bgr(got)
+    cen, hsv = grid_kmeans(bgr, k=1)
+    for c in (0, 137, 349):
+        X = O.preprocess_rgba(O.extract_cell(bgr, c)).reshape(-1, 4)
+        assert len(X) == 153 * 154
+        oc, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
+        assert np.array_equal(cen[c], np.rint(oc[0]))
