@@ -38,7 +38,7 @@ struct LloydScratch {
     int init()
     {
         if (ready) return OFC_OK;
-        constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1;
+        constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1 + LLOYD_DMAX;
         OFC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         OFC_TRY(state.alloc(sizeof(LloydState)));
         OFC_TRY(partial.alloc(sizeof(double) * 2048 * NVMAX));
@@ -64,7 +64,7 @@ static int relocate_empty(LloydScratch &sc, const void *X, int dtype, int64_t N,
                           int nblocks, const uint8_t *labels, const double *mean_h)
 {
     hipStream_t s = sc.stream;
-    const int NV = kmax * d + kmax + 1;
+    const int NV = lloyd_record_len(kmax, d);
     std::vector<double> tot(NV);
     OFC_HIP(hipMemcpyAsync(tot.data(), sc.tot.p, sizeof(double) * NV, hipMemcpyDeviceToHost, s));
     OFC_HIP(hipStreamSynchronize(s));
@@ -159,7 +159,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     }
     OFC_TRY(ensure_device(device));
     const int kmax = lloyd_kmax(k);
-    const int NV = kmax * d + kmax + 1;
+    const int NV = lloyd_record_len(kmax, d);
     LloydScratch &sc = scratch_for(device);
     OFC_TRY(sc.init());
     hipStream_t s = sc.stream;
@@ -188,13 +188,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     }
     for (int f = 0; f < d; f++) mean_h[f] = hbuf[f] / Ng;
     OFC_HIP(hipMemcpyAsync(st->mean, mean_h, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 1, sc.partial.as<double>(), nblocks, s));
-    OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
-    OFC_TRY(dist_allreduce_f64(tot, d, DIST_SUM, s));
-    OFC_HIP(hipMemcpyAsync(var_h, tot, sizeof(double) * d, hipMemcpyDeviceToHost, s));
-    OFC_HIP(hipStreamSynchronize(s));
-    for (int f = 0; f < d; f++) var_h[f] /= Ng;
-    const double tol = (tol_rel == 0) ? 0 : np_sum_small(var_h, d) / (double)d * tol_rel;
+    double tol = 0;      // mean(var) * tol_rel: the column sums of (x-mean)^2 ride along with the first iteration
 
     // ---- centred init ----
     double c0[LLOYD_KMAX * LLOYD_DMAX];
@@ -207,7 +201,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     bool strict = false;
     int it = 0;
     for (it = 0; it < max_iter; it++) {
-        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, true, s));
+        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 1, it == 0, s));
         OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s));
         OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
         OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, sc.status_dev, s));
@@ -217,14 +211,19 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             OFC_TRY(launch_lloyd_update(st, tot, k, d, 1, sc.status_dev, s));
             OFC_HIP(hipStreamSynchronize(s));
         }
+        if (it == 0 && tol_rel != 0) {
+            for (int f = 0; f < d; f++) var_h[f] = sc.status->sqsum[f] / Ng;
+            tol = np_sum_small(var_h, d) / (double)d * tol_rel;
+        }
         if (sc.status->n_changed == 0.0) { strict = true; break; }
         if (sc.status->shift_tot <= tol) break;
     }
     if (it == max_iter) it = max_iter - 1;
+    // ---- final E-step (only when not strictly converged) and inertia: one sweep ----
     if (!strict)
-        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, false, s));
-    // ---- inertia, un-centred centres ----
-    OFC_TRY(launch_lloyd_inertia(X, dtype, N, d, st, labels_dev, sc.partial.as<double>(), nblocks, s));
+        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 2, 0, s));
+    else
+        OFC_TRY(launch_lloyd_inertia(X, dtype, N, d, st, labels_dev, sc.partial.as<double>(), nblocks, s));
     OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, 1, tot, s));
     OFC_TRY(dist_allreduce_f64(tot, 1, DIST_SUM, s));
     double in = 0, cfin[LLOYD_KMAX * LLOYD_DMAX];
@@ -252,7 +251,7 @@ static int lloyd_predict_dev(int device, const void *X, int dtype, int64_t N, in
     OFC_HIP(hipMemcpy(st->centers, centers, sizeof(double) * k * d, hipMemcpyHostToDevice));
     OFC_TRY(launch_lloyd_set_centers(st, k, d, nullptr));
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
-    OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, false, nullptr));
+    OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, nullptr));
     OFC_HIP(hipStreamSynchronize(nullptr));
     return OFC_OK;
 }
@@ -332,12 +331,12 @@ int ofc_lloyd_step_dev(int device, const void *X_dev, int dtype, int64_t N, int 
     OFC_REQUIRE(X_dev && mean && centers_c && labels_dev && (record || !accumulate) && N >= 0, "bad arguments");
     OFC_TRY(check_kd(k, d));
     OFC_TRY(ensure_device(device));
-    const int kmax = lloyd_kmax(k), NV = kmax * d + kmax + 1;
+    const int kmax = lloyd_kmax(k), NV = lloyd_record_len(kmax, d);
     StepCtx c;
     OFC_TRY(c.init(N, NV));
     OFC_TRY(c.set(mean, centers_c, k, d));
     LloydState *st = c.state.as<LloydState>();
-    OFC_TRY(launch_lloyd_assign(X_dev, dtype, N, d, k, st, labels_dev, c.partial.as<double>(), c.nblocks, accumulate != 0, nullptr));
+    OFC_TRY(launch_lloyd_assign(X_dev, dtype, N, d, k, st, labels_dev, c.partial.as<double>(), c.nblocks, accumulate ? 1 : 0, 0, nullptr));
     if (accumulate) {
         OFC_TRY(launch_reduce_records(c.partial.as<double>(), c.nblocks, NV, c.tot.as<double>(), nullptr));
         std::vector<double> t(NV);

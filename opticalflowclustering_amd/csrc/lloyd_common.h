@@ -22,14 +22,18 @@ struct LloydStatus {
     int n_empty;
     int pad;
     double counts[LLOYD_KMAX];
+    double sqsum[LLOYD_DMAX];     // sum (x-mean)^2 per column (first iteration only)
 };
 
 int lloyd_kmax(int k);
 int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const double *mean, int pass,
                           double *partial, int nblocks, hipStream_t s);
 int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s);
+// mode 0: labels only; 1: labels + M-step record (+ column sums of (x-mean)^2 when first != 0); 2: labels + inertia
+// record = [kmax*d sums][kmax counts][n_changed][LLOYD_DMAX squared sums]
 int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
-                        uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s);
+                        uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s);
+inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + 1 + LLOYD_DMAX; }
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc,
                         LloydStatus *status, hipStream_t s);
 int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s);

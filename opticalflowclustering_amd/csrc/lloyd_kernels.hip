@@ -169,18 +169,36 @@ __device__ __forceinline__ int assign_point(const double (&x)[D], const double *
     return label;
 }
 
+template <int D>
+__device__ __forceinline__ double sq_euclid_grouped(const double (&a)[D], const double *b)
+{
+#pragma clang fp contract(off)
+    double r = 0;
+    int f = 0;
+#pragma unroll
+    for (; f + 4 <= D; f += 4)
+        r += ((a[f] - b[f]) * (a[f] - b[f]) + (a[f + 1] - b[f + 1]) * (a[f + 1] - b[f + 1]) +
+              (a[f + 2] - b[f + 2]) * (a[f + 2] - b[f + 2]) + (a[f + 3] - b[f + 3]) * (a[f + 3] - b[f + 3]));
+#pragma unroll
+    for (; f < D; f++) r += (a[f] - b[f]) * (a[f] - b[f]);
+    return r;
+}
+
 // The M-step partials are NOT kept as k*(d+1) predicated register accumulators (8 x 3 conditional f64 adds per
 // point made the kernel VALU-bound at 2.5 TB/s): every lane owns a private column of LDS accumulators
 // [k*d sums f64][k counts u32] x 256 lanes and adds each point into the slot of its label with one ds_add per
 // component.  A slot is only ever touched by its own lane, in point order, so the sums are deterministic; the
 // 256 columns are folded in a fixed order at the end.  LDS: k*(8d+4)*256 B (25 KB for k=5, d=2).
-template <int D, int KMAX, class T, bool ACCUM>
+// MODE 0: labels only (predict / final E-step); 1: labels + M-step partials (one Lloyd iteration; with `first` also
+// sum (x-mean)^2 per column for sklearn's tol, so that pass costs no extra sweep); 2: labels + inertia in one sweep.
+template <int D, int KMAX, class T, int MODE>
 __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k,
                                                       const LloydState *__restrict__ st,
                                                       uint8_t *__restrict__ labels,
-                                                      double *__restrict__ partial)
+                                                      double *__restrict__ partial, int first)
 {
-    constexpr int NV = KMAX * D + KMAX + 1;
+    constexpr bool ACCUM = (MODE == 1);
+    constexpr int NV = KMAX * D + KMAX + 1 + LLOYD_DMAX;     // [sums][counts][changed][sum (x-mean)^2 per column]
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                       // [k*D][256]
     unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
@@ -200,6 +218,9 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
         for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
     }
     unsigned changed = 0;
+    double sq[D], inert = 0;
+#pragma unroll
+    for (int f = 0; f < D; f++) sq[f] = 0;
     auto accumulate = [&](int l, const double (&x)[D]) {
 #pragma unroll
         for (int f = 0; f < D; f++) sacc[(l * D + f) * 256 + tid] += x[f];
@@ -225,6 +246,16 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
                 accumulate(nl[p], x[p]);
                 changed += (nl[p] != old[p]);
             }
+            if (first) {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int f = 0; f < D; f++) sq[f] += x[p][f] * x[p][f];
+            }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) inert += sq_euclid_grouped<D>(x[p], st->centers + nl[p] * D);
         }
         __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)), reinterpret_cast<unsigned *>(labels) + q);
     }
@@ -238,8 +269,18 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
         if (ACCUM) {
             accumulate(l, x);
             changed += (l != labels[i]);
+            if (first) {
+#pragma unroll
+                for (int f = 0; f < D; f++) sq[f] += x[f] * x[f];
+            }
         }
+        if (MODE == 2) inert += sq_euclid_grouped<D>(x, st->centers + l * D);
         labels[i] = (uint8_t)l;
+    }
+    if (MODE == 2) {
+        __shared__ double lds1[4];
+        double a1[1] = {inert};
+        block_reduce_store<1>(a1, lds1, partial + blockIdx.x);
     }
     if (ACCUM) {
         double *rec = partial + (size_t)blockIdx.x * NV;
@@ -262,7 +303,11 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
             for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
             if (lane == 0) rec[i < k * D ? i : KMAX * D + (i - k * D)] = a;
         }
-        if (tid == 0) rec[NV - 1] = (double)(s_changed[0] + s_changed[1] + s_changed[2] + s_changed[3]);
+        if (tid == 0) rec[KMAX * D + KMAX] = (double)(s_changed[0] + s_changed[1] + s_changed[2] + s_changed[3]);
+        if (first) {                                    // uniform
+            __shared__ double lds_sq[4 * D];
+            block_reduce_store<D>(sq, lds_sq, rec + KMAX * D + KMAX + 1);
+        }
     }
 }
 
@@ -336,6 +381,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
         for (int f = 0; f < d; f++) st->centers[j * d + f] = cnew[j * d + f];
     }
     status->n_changed = tot[kmax * d + kmax];
+    for (int f = 0; f < d; f++) status->sqsum[f] = tot[kmax * d + kmax + 1 + f];
     status->shift_tot = tot_shift;
     status->n_empty = 0;
     for (int j = 0; j < k; j++) status->counts[j] = w[j];
@@ -356,21 +402,6 @@ __global__ void k_lloyd_set_centers(LloydState *st, int k, int d)
 // inertia = sum ||x - c_label||^2 (centred), _inertia_dense grouping; partial[block][1]
 // and farthest-point search for empty-cluster relocation: partial[block] = {max dist, index}
 // ------------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ double sq_euclid_grouped(const double (&a)[D], const double *b)
-{
-#pragma clang fp contract(off)
-    double r = 0;
-    int f = 0;
-#pragma unroll
-    for (; f + 4 <= D; f += 4)
-        r += ((a[f] - b[f]) * (a[f] - b[f]) + (a[f + 1] - b[f + 1]) * (a[f + 1] - b[f + 1]) +
-              (a[f + 2] - b[f + 2]) * (a[f + 2] - b[f + 2]) + (a[f + 3] - b[f + 3]) * (a[f + 3] - b[f + 3]));
-#pragma unroll
-    for (; f < D; f++) r += (a[f] - b[f]) * (a[f] - b[f]);
-    return r;
-}
-
 template <int D, class T>
 __global__ __launch_bounds__(256) void k_lloyd_inertia(const T *__restrict__ X, int64_t N,
                                                        const LloydState *__restrict__ st,
@@ -447,29 +478,32 @@ int lloyd_kmax(int k) { return k <= 8 ? k : (k <= 16 ? 16 : 0); }
 
 template <int D, int KMAX, class T>
 static void launch_assign_t(const void *X, int64_t N, int k, const LloydState *st, uint8_t *labels,
-                            double *partial, int nblocks, bool accum, hipStream_t s)
+                            double *partial, int nblocks, int mode, int first, hipStream_t s)
 {
-    if (accum) {
+    if (mode == 1) {
         const size_t lds = (size_t)k * (8 * D + 4) * 256;
         if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd_assign<D, KMAX, T, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd_assign<D, KMAX, T, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, true>), dim3(nblocks), dim3(256), lds, s,
-                           (const T *)X, N, k, st, labels, partial);
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, 1>), dim3(nblocks), dim3(256), lds, s,
+                           (const T *)X, N, k, st, labels, partial, first);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, 2>), dim3(nblocks), dim3(256), 0, s,
+                           (const T *)X, N, k, st, labels, partial, 0);
     } else {
-        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, false>), dim3(nblocks), dim3(256), 0, s,
-                           (const T *)X, N, k, st, labels, partial);
+        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, 0>), dim3(nblocks), dim3(256), 0, s,
+                           (const T *)X, N, k, st, labels, partial, 0);
     }
 }
 
 template <int D, int KMAX>
 static int launch_assign_d(const void *X, int dtype, int64_t N, int k, const LloydState *st,
-                           uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s)
+                           uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s)
 {
     switch (dtype) {
-    case OFC_U8: launch_assign_t<D, KMAX, uint8_t>(X, N, k, st, labels, partial, nblocks, accum, s); break;
-    case OFC_F32: launch_assign_t<D, KMAX, float>(X, N, k, st, labels, partial, nblocks, accum, s); break;
-    case OFC_F64: launch_assign_t<D, KMAX, double>(X, N, k, st, labels, partial, nblocks, accum, s); break;
+    case OFC_U8: launch_assign_t<D, KMAX, uint8_t>(X, N, k, st, labels, partial, nblocks, mode, first, s); break;
+    case OFC_F32: launch_assign_t<D, KMAX, float>(X, N, k, st, labels, partial, nblocks, mode, first, s); break;
+    case OFC_F64: launch_assign_t<D, KMAX, double>(X, N, k, st, labels, partial, nblocks, mode, first, s); break;
     default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
     }
     OFC_HIP(hipGetLastError());
@@ -486,22 +520,22 @@ static int launch_assign_d(const void *X, int dtype, int64_t N, int k, const Llo
     }
 
 int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
-                        uint8_t *labels, double *partial, int nblocks, bool accum, hipStream_t s)
+                        uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s)
 {
     const int kmax = lloyd_kmax(k);
     if (!kmax) { set_error("k=%d unsupported by the streaming kernel (1..16)", k); return OFC_EUNSUPPORTED; }
     int rc = OFC_OK;
     OFC_D_SWITCH(d, {
         switch (kmax) {
-        case 1: rc = launch_assign_d<DD, 1>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 2: rc = launch_assign_d<DD, 2>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 3: rc = launch_assign_d<DD, 3>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 4: rc = launch_assign_d<DD, 4>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 5: rc = launch_assign_d<DD, 5>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 6: rc = launch_assign_d<DD, 6>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 7: rc = launch_assign_d<DD, 7>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        case 8: rc = launch_assign_d<DD, 8>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
-        default: rc = launch_assign_d<DD, 16>(X, dtype, N, k, st, labels, partial, nblocks, accum, s); break;
+        case 1: rc = launch_assign_d<DD, 1>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 2: rc = launch_assign_d<DD, 2>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 3: rc = launch_assign_d<DD, 3>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 4: rc = launch_assign_d<DD, 4>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 5: rc = launch_assign_d<DD, 5>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 6: rc = launch_assign_d<DD, 6>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 7: rc = launch_assign_d<DD, 7>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        case 8: rc = launch_assign_d<DD, 8>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
+        default: rc = launch_assign_d<DD, 16>(X, dtype, N, k, st, labels, partial, nblocks, mode, first, s); break;
         }
     })
     return rc;
