@@ -3,8 +3,8 @@
 // All kernels are batched over images / frame pairs through blockIdx.z so that even the coarse
 // pyramid levels (240x135 at 1080p) fill the 256 CUs.  Layouts in HBM:
 //   frames  [n][H0][W0] u8            pyramid image I [n][h][w] f32
-//   R       [n][5][h][w] f32 planar   (OpenCV's interleaved 5-float pixel is an internal detail;
-//                                      planar gives every lane dword/float4-coalesced stores)
+//   R       [n][h][w][5] f32 pixel-interleaved (5 coefficients = 20 contiguous bytes: the bilinear gather of the
+//                                      flow iteration reads 40-byte runs; producer stores stay fully coalesced)
 //   M       [p][5][h][w] f32 planar   flow [p][h][w][2] f32 (the ABI layout of cv2's output)
 //
 // Arithmetic follows the oracle (oracle/farneback_ref.c == SURVEY.md App. A) statement by statement.
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
                                                  PolyArgs p)
 {
     __shared__ __align__(16) float t[3][PE_CH][PE_PITCH];
+    __shared__ __align__(16) float stage[4][PE_TX * 5 + 16];   // per-wave output row (240 px x 5 coefficients)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = p.W, H = p.H;
     const int x0 = blockIdx.x * PE_TX;
@@ -448,22 +449,42 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
                     r2[o] = (float)((double)b1 * p.ig03 + (double)b5 * p.ig33);
                     r4[o] = b6 * (float)p.ig55;
                 }
-                float *o0 = out + (size_t)y * W + xo;
-                if (vec_ok) {   // W % 4 == 0 -> xo+3 < W and 16-B aligned
-                    typedef float v4f __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store((v4f){r0[0], r0[1], r0[2], r0[3]}, reinterpret_cast<v4f *>(o0));
-                    __builtin_nontemporal_store((v4f){r1[0], r1[1], r1[2], r1[3]}, reinterpret_cast<v4f *>(o0 + plane));
-                    __builtin_nontemporal_store((v4f){r2[0], r2[1], r2[2], r2[3]}, reinterpret_cast<v4f *>(o0 + 2 * plane));
-                    __builtin_nontemporal_store((v4f){r3[0], r3[1], r3[2], r3[3]}, reinterpret_cast<v4f *>(o0 + 3 * plane));
-                    __builtin_nontemporal_store((v4f){r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<v4f *>(o0 + 4 * plane));
+                // R is pixel-interleaved ([y][x][5], as OpenCV keeps it) so that the consumer's bilinear taps are two
+                // 40-byte runs instead of 20 scattered dwords.  A lane's 4 px x 5 coefficients are 80 contiguous bytes;
+                // storing them directly would make every wave-instruction write 16 B out of each 80 (measured: 5x
+                // slower).  They cross a per-wave LDS row instead (conflict-free at the 80-B lane stride) and leave as
+                // five fully contiguous 1-KiB wave stores.
+                if (vec_ok) {
+                    float *sg = &stage[wave][20 * lane];
+                    *reinterpret_cast<float4 *>(sg) = make_float4(r0[0], r1[0], r2[0], r3[0]);
+                    *reinterpret_cast<float4 *>(sg + 4) = make_float4(r4[0], r0[1], r1[1], r2[1]);
+                    *reinterpret_cast<float4 *>(sg + 8) = make_float4(r3[1], r4[1], r0[2], r1[2]);
+                    *reinterpret_cast<float4 *>(sg + 12) = make_float4(r2[2], r3[2], r4[2], r0[3]);
+                    *reinterpret_cast<float4 *>(sg + 16) = make_float4(r1[3], r2[3], r3[3], r4[3]);
                 } else {
+                    float *o0 = out + ((size_t)y * W + xo) * 5;
 #pragma unroll
                     for (int o = 0; o < 4; o++)
                         if (xo + o < W) {
-                            o0[o] = r0[o]; o0[plane + o] = r1[o]; o0[2 * plane + o] = r2[o];
-                            o0[3 * plane + o] = r3[o]; o0[4 * plane + o] = r4[o];
+                            o0[o * 5] = r0[o]; o0[o * 5 + 1] = r1[o]; o0[o * 5 + 2] = r2[o];
+                            o0[o * 5 + 3] = r3[o]; o0[o * 5 + 4] = r4[o];
                         }
                 }
+            }
+            if (vec_ok) {     // wave-uniform; the staging row belongs to this wave only
+                __builtin_amdgcn_wave_barrier();
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const int nf4 = min(PE_TX, W - x0) * 5 / 4;
+                v4f *orow = reinterpret_cast<v4f *>(out + ((size_t)y * W + x0) * 5);
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int idx = lane + 64 * j;
+                    if (idx < nf4) {
+                        const float4 v = lds_read4(&stage[wave][4 * idx]);
+                        __builtin_nontemporal_store((v4f){v.x, v.y, v.z, v.w}, orow + idx);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
@@ -517,7 +538,7 @@ struct UmIn {
     bool inr;
 };
 
-__device__ __forceinline__ void um_load(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
+__device__ __forceinline__ void um_load(const float *__restrict__ R0, const float *__restrict__ R1, size_t /*plane*/,
                                         int W, int H, int x, int y, float2 fl, UmIn &u)
 {
 #pragma clang fp contract(off)
@@ -527,12 +548,22 @@ __device__ __forceinline__ void um_load(const float *__restrict__ R0, const floa
     u.fx = fx - (float)x1;
     u.fy = fy - (float)y1;
     u.inr = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
-    const float *p = R1 + (u.inr ? (size_t)y1 * W + x1 : 0);
+    // R is pixel-interleaved: this pixel's 5 coefficients of R0 are 20 contiguous bytes; the two upper and the two lower
+    // bilinear taps of R1 are 40 contiguous bytes each.  dword-aligned vector loads (global_load_dwordx4/x2).
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    const float *q = R0 + idx * 5;
+    const f4u q0 = *reinterpret_cast<const f4u *>(q);
+    u.r0[0] = q0.x; u.r0[1] = q0.y; u.r0[2] = q0.z; u.r0[3] = q0.w; u.r0[4] = q[4];
+    const float *p = R1 + (u.inr ? ((size_t)y1 * W + x1) * 5 : 0);
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        u.g[0][c] = p[0]; u.g[1][c] = p[1]; u.g[2][c] = p[W]; u.g[3][c] = p[W + 1];
-        p += plane;
-        u.r0[c] = R0[c * plane + idx];
+    for (int rr = 0; rr < 2; rr++) {
+        const float *pr = p + (size_t)rr * W * 5;
+        const f4u a = *reinterpret_cast<const f4u *>(pr), b = *reinterpret_cast<const f4u *>(pr + 4);
+        const f2u c2 = *reinterpret_cast<const f2u *>(pr + 8);
+        u.g[2 * rr][0] = a.x; u.g[2 * rr][1] = a.y; u.g[2 * rr][2] = a.z; u.g[2 * rr][3] = a.w; u.g[2 * rr][4] = b.x;
+        u.g[2 * rr + 1][0] = b.y; u.g[2 * rr + 1][1] = b.z; u.g[2 * rr + 1][2] = b.w;
+        u.g[2 * rr + 1][3] = c2.x; u.g[2 * rr + 1][4] = c2.y;
     }
 }
 

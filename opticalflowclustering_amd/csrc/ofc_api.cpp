@@ -489,9 +489,7 @@ int ofc_polyexp(int device, const float *img, int W, int H, int n, double sigma,
     OFC_TRY(R.alloc(sizeof(float) * 5 * P));
     OFC_HIP(hipMemcpy(I.p, img, sizeof(float) * P, hipMemcpyHostToDevice));
     OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), 1, W, H, pc, 0, nullptr));
-    std::vector<float> planar(5 * P);
-    OFC_HIP(hipMemcpy(planar.data(), R.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));
-    interleave5(planar.data(), P, R5);
+    OFC_HIP(hipMemcpy(R5, R.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));   // already pixel-interleaved
     return OFC_OK;
 }
 
@@ -502,14 +500,13 @@ int ofc_update_matrices(int device, const float *R0, const float *R1, const floa
     OFC_REQUIRE(W >= 2 && H >= 2, "bad size");
     OFC_TRY(ensure_device(device));
     const size_t P = (size_t)W * H;
-    std::vector<float> tmp(10 * P);
-    planarize5(R0, P, tmp.data());
-    planarize5(R1, P, tmp.data() + 5 * P);
+    std::vector<float> tmp(5 * P);
     DevBuf dR, dF, dM;
     OFC_TRY(dR.alloc(sizeof(float) * 10 * P));
     OFC_TRY(dF.alloc(sizeof(float) * 2 * P));
     OFC_TRY(dM.alloc(sizeof(float) * 5 * P));
-    OFC_HIP(hipMemcpy(dR.p, tmp.data(), sizeof(float) * 10 * P, hipMemcpyHostToDevice));
+    OFC_HIP(hipMemcpy(dR.p, R0, sizeof(float) * 5 * P, hipMemcpyHostToDevice));                       // R is pixel-interleaved
+    OFC_HIP(hipMemcpy(dR.as<float>() + 5 * P, R1, sizeof(float) * 5 * P, hipMemcpyHostToDevice));
     OFC_HIP(hipMemcpy(dF.p, flow, sizeof(float) * 2 * P, hipMemcpyHostToDevice));
     OFC_TRY(launch_update_matrices(dR.as<float>(), dR.as<float>() + 5 * P, 5 * P, dF.as<float>(),
                                    dM.as<float>(), 1, W, H, nullptr));
