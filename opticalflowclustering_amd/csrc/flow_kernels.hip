@@ -954,15 +954,22 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                             S[c][o] = s;
                         }
                     }
+                    float2 fo[4];
 #pragma unroll
                     for (int o = 0; o < 4; o++) {
-                        if (4 * lane + o < TXO && xo + o < W) {
-                            const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
-                                         h1 = S[3][o] * scale, h2 = S[4][o] * scale;
-                            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                            flow_out[(size_t)y * W + xo + o] =
-                                make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
-                        }
+                        const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                     h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        fo[o] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                    }
+                    float2 *dst = flow_out + (size_t)y * W + xo;
+                    if (4 * lane + 3 < TXO && xo + 3 < W && (W & 1) == 0) {      // 32 contiguous, 16-B aligned bytes
+                        reinterpret_cast<float4 *>(dst)[0] = make_float4(fo[0].x, fo[0].y, fo[1].x, fo[1].y);
+                        reinterpret_cast<float4 *>(dst)[1] = make_float4(fo[2].x, fo[2].y, fo[3].x, fo[3].y);
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+                            if (4 * lane + o < TXO && xo + o < W) dst[o] = fo[o];
                     }
                 }
             }
