@@ -788,8 +788,21 @@ __device__ __forceinline__ float2 upsampled_flow(const float2 *__restrict__ s, i
 #pragma clang fp contract(off)
     int sx0, sy0, sy1;
     float a1, b1;
-    lin_tap_x(x, scx, sw, sx0, a1);
-    lin_tap_y(y, scy, sh, sy0, sy1, b1);
+    if (scx == 0.5 && scy == 0.5) {
+        // exact x2 (the reference's pyr_scale 0.5 on even sizes): (d+0.5)*0.5-0.5 = 0.5d-0.25 is exact in f32 too,
+        // so the taps come from integer arithmetic instead of two f64 evaluations per pixel -- same values
+        const int sx = (x + 1) / 2 - 1, sy = (y + 1) / 2 - 1;          // floor(0.5d - 0.25)
+        a1 = (x & 1) ? 0.25f : 0.75f;
+        b1 = (y & 1) ? 0.25f : 0.75f;
+        sx0 = sx;
+        if (sx < 0) { a1 = 0.f; sx0 = 0; }
+        if (sx >= sw - 1) { a1 = 0.f; sx0 = sw - 1; }
+        sy0 = min(max(sy, 0), sh - 1);
+        sy1 = min(max(sy + 1, 0), sh - 1);
+    } else {
+        lin_tap_x(x, scx, sw, sx0, a1);
+        lin_tap_y(y, scy, sh, sy0, sy1, b1);
+    }
     const float a0 = 1.f - a1, b0 = 1.f - b1;
     const int sx1 = (a1 == 0.f) ? sx0 : sx0 + 1;
     const float2 p00 = s[(size_t)sy0 * sw + sx0], p01 = s[(size_t)sy0 * sw + sx1];
