@@ -214,6 +214,14 @@ int ofc_dist_init(int device, int rank, int world, const uint8_t id[OFC_UNIQUE_I
 int ofc_dist_allreduce_f64(int device, double *buf_dev, int count); /* test hook */
 int ofc_dist_finalize(void);
 
+/* ------------------------------------------------------------------------------------------
+ * Downstream consumer of the hue CSVs (findCosineDifferentVectors.py:5-61): cosine similarity between
+ * `small` (n_small values) and every window large[i : i+n_small], i = 0 .. n_large-n_small.
+ * sims has n_large-n_small+1 entries; 0 where either norm is 0.  Integer-valued input is summed exactly.
+ * ------------------------------------------------------------------------------------------ */
+int ofc_sliding_cosine(int device, const double *small_v, int n_small, const double *large_v, int n_large,
+                       double *sims);
+
 /* ---- synthetic input generator used by bench.py (not part of the reference path) ---- */
 int ofc_synth_frames_dev(int device, uint8_t *frames_dev, int W, int H, int n_frames,
                          int t0, int seed);

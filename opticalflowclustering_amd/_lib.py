@@ -82,6 +82,7 @@ _PROTOS = {
     "ofc_dist_init": ([_i, _i, _i, _vp], _i),
     "ofc_dist_allreduce_f64": ([_i, _vp, _i], _i),
     "ofc_dist_finalize": ([], _i),
+    "ofc_sliding_cosine": ([_i, _vp, _i, _vp, _i, _vp], _i),
     "ofc_synth_frames_dev": ([_i, _vp, _i, _i, _i, _i, _i], _i),
 }
 EXPORTS = tuple(_PROTOS)

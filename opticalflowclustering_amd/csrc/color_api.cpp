@@ -191,6 +191,26 @@ int ofc_grid_kmeans(int device, const uint8_t *bgr, int W, int H, int rows, int 
                                channel_order, centers, hsv);
 }
 
+int ofc_sliding_cosine(int device, const double *small_v, int n_small, const double *large_v, int n_large, double *sims)
+{
+    OFC_REQUIRE(small_v && large_v && sims, "null pointer");
+    OFC_REQUIRE(n_small >= 1 && n_large >= n_small, "need 1 <= n_small <= n_large (got %d, %d)", n_small, n_large);
+    OFC_TRY(ensure_device(device));
+    const int nwin = n_large - n_small + 1;
+    int all_int = 1;
+    for (int i = 0; i < n_small && all_int; i++) all_int = std::fabs(small_v[i]) < 2147483648.0 && small_v[i] == std::floor(small_v[i]);
+    for (int i = 0; i < n_large && all_int; i++) all_int = std::fabs(large_v[i]) < 2147483648.0 && large_v[i] == std::floor(large_v[i]);
+    DevBuf a, b, o;
+    OFC_TRY(a.alloc(sizeof(double) * n_small));
+    OFC_TRY(b.alloc(sizeof(double) * n_large));
+    OFC_TRY(o.alloc(sizeof(double) * nwin));
+    OFC_HIP(hipMemcpy(a.p, small_v, sizeof(double) * n_small, hipMemcpyHostToDevice));
+    OFC_HIP(hipMemcpy(b.p, large_v, sizeof(double) * n_large, hipMemcpyHostToDevice));
+    OFC_TRY(launch_sliding_cosine(a.as<double>(), n_small, b.as<double>(), nwin, o.as<double>(), all_int, nullptr));
+    OFC_HIP(hipMemcpy(sims, o.p, sizeof(double) * nwin, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
 int ofc_synth_frames_dev(int device, uint8_t *frames_dev, int W, int H, int n_frames, int t0, int seed)
 {
     OFC_REQUIRE(frames_dev && W >= 1 && H >= 1 && n_frames >= 1, "bad arguments");

@@ -302,6 +302,58 @@ int launch_grid_cell_means(const uint8_t *bgr, int W, int H, int nframes, int ro
 }
 
 // ------------------------------------------------------------------------------------------------
+// sliding-window cosine similarity (findCosineDifferentVectors.py:5-61): one work-group per window offset.
+// np.dot / np.linalg.norm on the integer hue columns are exact integer sums; a value v with |v| < 2^31 and integral
+// goes through the int64 accumulators, anything else through f64 (tree order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sliding_cosine(const double *__restrict__ a, int na,
+                                                        const double *__restrict__ b, double *__restrict__ sims,
+                                                        int all_int)
+{
+    __shared__ double sd[3][4];
+    __shared__ long long si[3][4];
+    const double *w = b + blockIdx.x;
+    double fd = 0, fa = 0, fb = 0;
+    long long id = 0, ia = 0, ib = 0;
+    for (int i = threadIdx.x; i < na; i += 256) {
+        if (all_int) {
+            const long long x = (long long)a[i], y = (long long)w[i];
+            id += x * y; ia += x * x; ib += y * y;
+        } else {
+            fd += a[i] * w[i]; fa += a[i] * a[i]; fb += w[i] * w[i];
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        fd += __shfl_down(fd, off, 64); fa += __shfl_down(fa, off, 64); fb += __shfl_down(fb, off, 64);
+        id += __shfl_down(id, off, 64); ia += __shfl_down(ia, off, 64); ib += __shfl_down(ib, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sd[0][wave] = fd; sd[1][wave] = fa; sd[2][wave] = fb; si[0][wave] = id; si[1][wave] = ia; si[2][wave] = ib; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double dot, na2, nb2;
+        if (all_int) {
+            dot = (double)(si[0][0] + si[0][1] + si[0][2] + si[0][3]);
+            na2 = (double)(si[1][0] + si[1][1] + si[1][2] + si[1][3]);
+            nb2 = (double)(si[2][0] + si[2][1] + si[2][2] + si[2][3]);
+        } else {
+            dot = ((sd[0][0] + sd[0][1]) + sd[0][2]) + sd[0][3];
+            na2 = ((sd[1][0] + sd[1][1]) + sd[1][2]) + sd[1][3];
+            nb2 = ((sd[2][0] + sd[2][1]) + sd[2][2]) + sd[2][3];
+        }
+        const double n1 = sqrt(na2), n2 = sqrt(nb2);
+        sims[blockIdx.x] = (n1 == 0 || n2 == 0) ? 0.0 : dot / (n1 * n2);
+    }
+}
+
+int launch_sliding_cosine(const double *a, int na, const double *b, int nwin, double *sims, int all_int, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sliding_cosine, dim3(nwin), dim3(256), 0, s, a, na, b, sims, all_int);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic frames for bench.py (not part of the reference path): analytic multi-sinusoid texture,
 // five motion populations in vertical bands, frame t displaced by t * velocity.
 // ------------------------------------------------------------------------------------------------

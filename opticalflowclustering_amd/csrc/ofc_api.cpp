@@ -441,7 +441,8 @@ int ofc_flow_last_vis_dev(ofc_flow_t *f, const uint8_t **vis_dev)
 }
 
 // =================================================================================================
-// single stages (host buffers; parity-test hooks).  Interleaved <-> planar conversion on the host.
+// single stages (host buffers; parity-test hooks).  R is pixel-interleaved on the device as well; only M (planar in
+// the staged fallback kernels) is converted on the host.
 // =================================================================================================
 static void interleave5(const float *planar, size_t P, float *inter)
 {

@@ -86,10 +86,10 @@ void polyexp_setup(int n, double sigma, PolyConsts &c);        // FarnebackPrepa
 // src: [nimg][H0][W0] u8 -> dst: [nimg][h][w] f32
 int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
                        const LevelGeom &g, hipStream_t s);
-// I: [nimg][H][W] f32 -> R: [nimg][5][H][W] f32 (planar)
+// I: [nimg][H][W] f32 -> R: [nimg][H][W][5] f32 (pixel-interleaved)
 int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
                    int rows_per_block, hipStream_t s, bool bench_tag = false);
-// R0 = R + pair*strideR, R1 = R0 + strideR (consecutive frames); flow [npair][H][W][2]; M [npair][5][H][W]
+// R0 = R + pair*strideR, R1 = R0 + strideR (consecutive frames, interleaved); flow [npair][H][W][2]; M [npair][5][H][W] planar
 int launch_update_matrices(const float *R0, const float *R1, size_t pair_stride_R,
                            const float *flow, float *M, int npair, int W, int H, hipStream_t s);
 int launch_box_solve(const float *M, float *flow, int npair, int W, int H, int winsize,

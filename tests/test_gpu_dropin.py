@@ -167,3 +167,22 @@ def test_clip_pipeline_and_sharded_driver_agree_with_library_fit():
     c2, i2, n2 = fit_sharded(shard, init)
     assert n2 == on and np.abs(c2 - oc).max() <= 1e-9 and abs(i2 - oi) <= 1e-10 * oi
     pipe.close()
+
+
+def test_find_cosine_matches_reference_run():
+    """golden = stdout of the reference's own findCosineDifferentVectors.py on its recorded hue CSVs
+    (tests/golden/make_cosine_golden.py)"""
+    import json
+    from opticalflowclustering_amd import findCosineDifferentVectors as F
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cosine_kat.json")))
+    assert len(cases) >= 3
+    for c in cases:
+        sim, frame = F.find_max(np.array(c["small_hue"]), np.array(c["large_hue"]))
+        assert frame == c["max_frame"]
+        assert sim == c["max_similarity"], (sim, c["max_similarity"])     # exact: integer sums, one sqrt/divide
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(40), rng.standard_normal(500)              # non-integer path
+    sims = F.sliding_cosine(a, b)
+    ref = [np.dot(a, b[i:i + 40]) / (np.linalg.norm(a) * np.linalg.norm(b[i:i + 40])) for i in range(461)]
+    assert np.abs(sims - ref).max() < 1e-14
+    assert F.sliding_cosine(np.zeros(3), np.arange(5.0)).tolist() == [0.0, 0.0, 0.0]
