@@ -215,6 +215,24 @@ int ofc_dist_allreduce_f64(int device, double *buf_dev, int count); /* test hook
 int ofc_dist_finalize(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Streaming ingest (BASELINE.json configs[4] shape): frames arrive from the host one at a time (a decoder);
+ * they are packed into pinned ring buffers, uploaded with hipMemcpyAsync on a copy stream while the previous batch
+ * computes, and reduced on the device to the grid-cell averaged flow: per pair rows*cols (u,v) means.
+ * No reference counterpart beyond the cv2.VideoCapture loop (KmeanGrids.py:180-187); the grid geometry is
+ * overlayGridAndComputeAvgColor's (KmeanGrids.py:56-59).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ofc_stream ofc_stream_t;
+int ofc_stream_create(int device, int W, int H, const ofc_fb_params *p, int batch_pairs, int rows, int cols,
+                      ofc_stream_t **out);
+/* push one HxW u8 frame; *pairs_done = pairs whose cell means are complete so far (may lag the pushes) */
+int ofc_stream_push_gray(ofc_stream_t *s, const uint8_t *gray, int *pairs_done);
+/* flush the partial batch, wait, and copy all cell means out: cell_uv[n_pairs][rows*cols][2] f32 */
+int ofc_stream_finish(ofc_stream_t *s, float *cell_uv, int max_pairs, int *n_pairs);
+void ofc_stream_destroy(ofc_stream_t *s);
+/* per-cell mean of a flow field (host buffers): flow HxWx2 f32 -> cell_uv rows*cols x 2 f32 */
+int ofc_grid_cell_mean_flow(int device, const float *flow, int W, int H, int rows, int cols, float *cell_uv);
+
+/* ------------------------------------------------------------------------------------------
  * Downstream consumer of the hue CSVs (findCosineDifferentVectors.py:5-61): cosine similarity between
  * `small` (n_small values) and every window large[i : i+n_small], i = 0 .. n_large-n_small.
  * sims has n_large-n_small+1 entries; 0 where either norm is 0.  Integer-valued input is summed exactly.

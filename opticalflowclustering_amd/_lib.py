@@ -82,6 +82,11 @@ _PROTOS = {
     "ofc_dist_init": ([_i, _i, _i, _vp], _i),
     "ofc_dist_allreduce_f64": ([_i, _vp, _i], _i),
     "ofc_dist_finalize": ([], _i),
+    "ofc_stream_create": ([_i, _i, _i, C.POINTER(FbParams), _i, _i, _i, C.POINTER(_vp)], _i),
+    "ofc_stream_push_gray": ([_vp, _vp, _ip], _i),
+    "ofc_stream_finish": ([_vp, _vp, _i, _ip], _i),
+    "ofc_stream_destroy": ([_vp], None),
+    "ofc_grid_cell_mean_flow": ([_i, _vp, _i, _i, _i, _i, _vp], _i),
     "ofc_sliding_cosine": ([_i, _vp, _i, _vp, _i, _vp], _i),
     "ofc_synth_frames_dev": ([_i, _vp, _i, _i, _i, _i, _i], _i),
 }

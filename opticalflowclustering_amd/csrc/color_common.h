@@ -38,6 +38,7 @@ int launch_flow_to_bgr(const float *flow, int W, int H, int nframes, uint8_t *bg
                        double *partial, VisFrameStats *stats, hipStream_t s);
 int launch_grid_cell_means(const uint8_t *bgr, int W, int H, int nframes, int rows, int cols,
                            uint8_t *mean_bgr, uint8_t *hsv, hipStream_t s);
+int launch_grid_cell_mean_flow(const float *flow, int W, int H, int npair, int rows, int cols, float *out, hipStream_t s);
 int launch_sliding_cosine(const double *a, int na, const double *b, int nwin, double *sims, int all_int, hipStream_t s);
 int launch_synth_frames(uint8_t *frames, int W, int H, int nframes, int t0, const SynthParams &sp, hipStream_t s);
 

@@ -302,6 +302,42 @@ int launch_grid_cell_means(const uint8_t *bgr, int W, int H, int nframes, int ro
 }
 
 // ------------------------------------------------------------------------------------------------
+// grid-cell averaged flow: per cell the mean (u, v) over its x_step x y_step pixels (f64 sums, f32 result).
+// One work-group per (cell, pair); 8 B/px read.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_cell_mean_flow(const float2 *__restrict__ flow, int W, int H, int rows,
+                                                             int cols, float2 *__restrict__ out)
+{
+    __shared__ double su[4], sv[4];
+    const int cell = blockIdx.x, cy = cell / cols, cx = cell % cols;
+    const int xs = W / cols, ys = H / rows;
+    const float2 *f = flow + (size_t)blockIdx.y * W * H;
+    double u = 0, v = 0;
+    for (int i = threadIdx.x; i < xs * ys; i += 256) {
+        const int ly = i / xs, lx = i - ly * xs;
+        const float2 p = f[(size_t)(cy * ys + ly) * W + cx * xs + lx];
+        u += (double)p.x; v += (double)p.y;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { u += __shfl_down(u, off, 64); v += __shfl_down(v, off, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { su[wave] = u; sv[wave] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)xs * ys;
+        out[(size_t)blockIdx.y * rows * cols + cell] =
+            make_float2((float)((((su[0] + su[1]) + su[2]) + su[3]) / n), (float)((((sv[0] + sv[1]) + sv[2]) + sv[3]) / n));
+    }
+}
+
+int launch_grid_cell_mean_flow(const float *flow, int W, int H, int npair, int rows, int cols, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_cell_mean_flow, dim3(rows * cols, npair), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(flow), W, H, rows, cols, reinterpret_cast<float2 *>(out));
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // sliding-window cosine similarity (findCosineDifferentVectors.py:5-61): one work-group per window offset.
 // np.dot / np.linalg.norm on the integer hue columns are exact integer sums; a value v with |v| < 2^31 and integral
 // goes through the int64 accumulators, anything else through f64 (tree order).

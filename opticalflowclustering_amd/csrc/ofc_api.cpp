@@ -352,6 +352,8 @@ int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_fra
     return flow_run(f, frames_dev, n_frames, flow_dev);
 }
 
+hipStream_t ofc_flow_stream_internal(ofc_flow_t *f) { return f->stream; }   // for stream_api.cpp (not exported in ofc.h)
+
 int ofc_flow_sync(ofc_flow_t *f)
 {
     OFC_REQUIRE(f, "null pointer");

@@ -186,3 +186,36 @@ def test_find_cosine_matches_reference_run():
     ref = [np.dot(a, b[i:i + 40]) / (np.linalg.norm(a) * np.linalg.norm(b[i:i + 40])) for i in range(461)]
     assert np.abs(sims - ref).max() < 1e-14
     assert F.sliding_cosine(np.zeros(3), np.arange(5.0)).tolist() == [0.0, 0.0, 0.0]
+
+
+def test_streaming_ingest_cell_averaged_flow_and_kmeans():
+    """configs[4] shape at test size: pushed frames -> double-buffered upload -> flow -> 14x25 cell-averaged (u,v)
+    -> k-means(k=8); against the oracle's flow averaged with numpy and the oracle's Lloyd"""
+    from opticalflowclustering_amd.cluster import KMeans
+    from opticalflowclustering_amd.stream import FlowStream, grid_cell_mean_flow
+    W, H, T = 700, 420, 11
+    p = synth.texture_params(4)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    frames = [synth.frame(W, H, 0.9 * t + 0.6 * t * np.sin(2 * np.pi * yy / H), -0.5 * t + 0.4 * t * np.cos(2 * np.pi * xx / W), p)
+              for t in range(T)]                       # smooth non-rigid motion growing with t
+    st = FlowStream(W, H, batch_pairs=4)
+    for f in frames:
+        st.push(f)
+    cells = st.finish()
+    st.close()
+    assert cells.shape == (T - 1, 350, 2)
+    xs, ys = W // 25, H // 14
+    want = []
+    for t in range(T - 1):
+        fl = O.farneback(frames[t], frames[t + 1])
+        m = fl[:ys * 14, :xs * 25].reshape(14, ys, 25, xs, 2).astype(np.float64).mean((1, 3)).reshape(350, 2)
+        want.append(m)
+        if t == 0:
+            assert np.abs(grid_cell_mean_flow(fl) - m).max() <= 1e-6 * max(1.0, np.abs(m).max())
+    want = np.stack(want)
+    assert np.abs(cells - want).max() <= 2e-4          # cell means of flows that agree to <= 1e-3 px
+    X = cells.reshape(-1, 2)
+    C0 = X[np.random.default_rng(0).choice(len(X), 8, replace=False)].astype(np.float64)
+    km = KMeans(n_clusters=8, init=C0).fit(X)
+    oc, ol, _, on = O.kmeans_fit(X, C0)
+    assert km.n_iter_ == on and np.array_equal(km.labels_, ol) and np.abs(km.cluster_centers_ - oc).max() <= 1e-9

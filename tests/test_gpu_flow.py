@@ -170,3 +170,24 @@ def test_flow_4k_pair_and_grid_cells():
         assert len(X) == 153 * 154
         oc, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
         assert np.array_equal(cen[c], np.rint(oc[0]))
+
+
+def test_flow_on_unrelated_content_stays_within_relative_bar():
+    """a pair whose second frame is NOT a plausible motion of the first (band-wise displacements up to 12 px with hard
+    discontinuities): the solve is near-singular in places and 1-ulp differences (FMA vs separate mul/add in the
+    polynomial expansion, exact vs running box sums) are amplified.  north_star's bar -- 1e-4 relative per frame --
+    still holds (measured 3.8e-5); the absolute per-pixel bound of the well-posed cases does not (measured max 1e-2 px
+    on 0.6 % of the pixels), so only a loose sanity bound is asserted on it."""
+    from opticalflowclustering_amd.flow import FlowEngine
+    W, H = 700, 420
+    p = synth.texture_params(4)
+    a = synth.frame(W, H, 2.7, -1.5, p)
+    dx, dy, _ = synth.population_motion(W, H, 3, seed=3)
+    b = synth.frame(W, H, dx, dy, p)
+    eng = FlowEngine(W, H)
+    got = eng.calc(a, b)
+    eng.close()
+    want = O.farneback(a, b)
+    assert rel(got, want) <= 1e-4
+    assert np.abs(got - want).max() <= 0.1
+    assert (np.abs(got - want).max(-1) > 1e-3).mean() < 0.02
