@@ -195,18 +195,30 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     for (int j = 0; j < k * d; j++) c0[j] = init[j] - mean_h[j % d];
     OFC_HIP(hipMemcpyAsync(st->centers, c0, sizeof(double) * k * d, hipMemcpyHostToDevice, s));
     OFC_TRY(launch_lloyd_set_centers(st, k, d, s));
-    OFC_HIP(hipMemsetAsync(labels_dev, 0xFF, (size_t)N, s));
-
     // ---- Lloyd iterations ----
-    bool strict = false;
+    // sklearn stops on `labels == labels_old` (strict) before it looks at the centre shift (_kmeans.py:716-728).  While
+    // no cluster is empty that test is redundant: equal labels give bit-equal sums (fixed reduction order), hence
+    // centers_new == centers, shift_tot == 0 <= tol, and the tol test stops in the SAME iteration; the E-step sklearn
+    // then repeats (mode 2 below) reproduces the labels.  So the iterations stream X only (mode 3: no label read or
+    // write, 8 instead of 10 B/point for float2 data).  The labelled form (mode 1) takes over from the first
+    // iteration that meets an empty cluster: relocation needs the labels, and a relocated centre breaks the
+    // equal-labels => zero-shift argument.  That iteration itself cannot be a strict stop: equal labels would mean the
+    // previous iteration had the same empty cluster.
+    bool strict = false, labelled = false;
     int it = 0;
     for (it = 0; it < max_iter; it++) {
-        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 1, it == 0, s));
+        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, labelled ? 1 : 3,
+                                    it == 0, s));
         OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s));
         OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
         OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, sc.status_dev, s));
         OFC_HIP(hipStreamSynchronize(s));
+        const bool was_labelled = labelled;
         if (sc.status->n_empty > 0) {
+            if (!labelled) {       // materialise this iteration's labels (st->centers is still the E-step's input)
+                OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, s));
+                labelled = true;
+            }
             OFC_TRY(relocate_empty(sc, X, dtype, N, d, k, kmax, nblocks, labels_dev, mean_h));
             OFC_TRY(launch_lloyd_update(st, tot, k, d, 1, sc.status_dev, s));
             OFC_HIP(hipStreamSynchronize(s));
@@ -215,7 +227,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             for (int f = 0; f < d; f++) var_h[f] = sc.status->sqsum[f] / Ng;
             tol = np_sum_small(var_h, d) / (double)d * tol_rel;
         }
-        if (sc.status->n_changed == 0.0) { strict = true; break; }
+        if (was_labelled && sc.status->n_changed == 0.0) { strict = true; break; }
         if (sc.status->shift_tot <= tol) break;
     }
     if (it == max_iter) it = max_iter - 1;

@@ -29,7 +29,8 @@ int lloyd_kmax(int k);
 int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const double *mean, int pass,
                           double *partial, int nblocks, hipStream_t s);
 int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s);
-// mode 0: labels only; 1: labels + M-step record (+ column sums of (x-mean)^2 when first != 0); 2: labels + inertia
+// mode 0: labels only; 1: labels + M-step record (+ column sums of (x-mean)^2 when first != 0); 2: labels + inertia;
+// 3: M-step record only (labels untouched, n_changed = 0)
 // record = [kmax*d sums][kmax counts][n_changed][LLOYD_DMAX squared sums]
 int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
                         uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s);

@@ -190,14 +190,16 @@ __device__ __forceinline__ double sq_euclid_grouped(const double (&a)[D], const 
 // component.  A slot is only ever touched by its own lane, in point order, so the sums are deterministic; the
 // 256 columns are folded in a fixed order at the end.  LDS: k*(8d+4)*256 B (25 KB for k=5, d=2).
 // MODE 0: labels only (predict / final E-step); 1: labels + M-step partials (one Lloyd iteration; with `first` also
-// sum (x-mean)^2 per column for sklearn's tol, so that pass costs no extra sweep); 2: labels + inertia in one sweep.
+// sum (x-mean)^2 per column for sklearn's tol, so that pass costs no extra sweep); 2: labels + inertia in one sweep;
+// 3: M-step partials only -- labels are neither read nor written (2 of the 10 B/point of a float2 stream), record's
+// n_changed slot is 0: lloyd_fit_dev's loop does not need it while no cluster is empty (see there).
 template <int D, int KMAX, class T, int MODE>
 __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k,
                                                       const LloydState *__restrict__ st,
                                                       uint8_t *__restrict__ labels,
                                                       double *__restrict__ partial, int first)
 {
-    constexpr bool ACCUM = (MODE == 1);
+    constexpr bool ACCUM = (MODE == 1 || MODE == 3), LABELS = (MODE != 3);
     constexpr int NV = KMAX * D + KMAX + 1 + LLOYD_DMAX;     // [sums][counts][changed][sum (x-mean)^2 per column]
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                       // [k*D][256]
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < n4; q += (int64_t)gridDim.x * 256) {
         double x[4][D];
         load4<D>(X, q * 4, x);
-        const unsigned lo = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q);
+        const unsigned lo = MODE == 1 ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q) : 0u;
         const int old[4] = {(int)(lo & 255u), (int)((lo >> 8) & 255u), (int)((lo >> 16) & 255u), (int)(lo >> 24)};
         int nl[4];
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 accumulate(nl[p], x[p]);
-                changed += (nl[p] != old[p]);
+                if (MODE == 1) changed += (nl[p] != old[p]);
             }
             if (first) {
 #pragma unroll
@@ -257,7 +259,9 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
 #pragma unroll
             for (int p = 0; p < 4; p++) inert += sq_euclid_grouped<D>(x[p], st->centers + nl[p] * D);
         }
-        __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)), reinterpret_cast<unsigned *>(labels) + q);
+        if (LABELS)
+            __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)),
+                                        reinterpret_cast<unsigned *>(labels) + q);
     }
     if (blockIdx.x == 0 && tid < (int)(N - n4 * 4)) {
         const int64_t i = n4 * 4 + tid;
@@ -268,14 +272,14 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
         const int l = assign_point<D, KMAX>(x, c, cn, k);
         if (ACCUM) {
             accumulate(l, x);
-            changed += (l != labels[i]);
+            if (MODE == 1) changed += (l != labels[i]);
             if (first) {
 #pragma unroll
                 for (int f = 0; f < D; f++) sq[f] += x[f] * x[f];
             }
         }
         if (MODE == 2) inert += sq_euclid_grouped<D>(x, st->centers + l * D);
-        labels[i] = (uint8_t)l;
+        if (LABELS) labels[i] = (uint8_t)l;
     }
     if (MODE == 2) {
         __shared__ double lds1[4];
@@ -480,13 +484,13 @@ template <int D, int KMAX, class T>
 static void launch_assign_t(const void *X, int64_t N, int k, const LloydState *st, uint8_t *labels,
                             double *partial, int nblocks, int mode, int first, hipStream_t s)
 {
-    if (mode == 1) {
+    if (mode == 1 || mode == 3) {
         const size_t lds = (size_t)k * (8 * D + 4) * 256;
+        auto kern = mode == 1 ? &k_lloyd_assign<D, KMAX, T, 1> : &k_lloyd_assign<D, KMAX, T, 3>;
         if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd_assign<D, KMAX, T, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, 1>), dim3(nblocks), dim3(256), lds, s,
-                           (const T *)X, N, k, st, labels, partial, first);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, s, (const T *)X, N, k, st, labels, partial, first);
     } else if (mode == 2) {
         hipLaunchKernelGGL((k_lloyd_assign<D, KMAX, T, 2>), dim3(nblocks), dim3(256), 0, s,
                            (const T *)X, N, k, st, labels, partial, 0);
