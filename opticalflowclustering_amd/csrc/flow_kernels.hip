@@ -347,7 +347,7 @@ constexpr int PE_N = 5;
 constexpr int PE_TX = 240;
 constexpr int PE_VW = PE_TX + 2 * PE_N;   // 250
 constexpr int PE_CH = 8;
-constexpr int PE_PITCH = 256;
+constexpr int PE_PLANE = 66;    // float4 per (row, pixel & 3) plane of the moments tile: 64 + 2 -> bank-staggered
 
 struct PolyArgs {
     int W, H, rows_per_block;
@@ -360,8 +360,14 @@ template <int TAG>
 __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
                                                  PolyArgs p)
 {
-    __shared__ __align__(16) float t[3][PE_CH][PE_PITCH];
+    // vertical moments of the chunk, one float4 (t0, t1, t2, t1) per pixel: the horizontal pass consumes them as the
+    // register pairs (t0,t1) and (t2,t1), which is what lets it run on packed-f32 instructions.  Pixel p of the strip
+    // lives at [p & 3][p >> 2]: lane l of the horizontal pass reads pixels 4l+j, so for a fixed j the 64 lanes touch 64
+    // consecutive float4 of one plane (conflict-free ds_read_b128); planes are 66 float4 apart (264 dwords = 8 mod 32
+    // banks) so that the vertical pass's writes, lane <-> pixel, spread over the banks as well.
+    __shared__ __align__(16) float4 t4[PE_CH][4][PE_PLANE];
     __shared__ __align__(16) float stage[4][PE_TX * 5 + 16];   // per-wave output row (240 px x 5 coefficients)
+    typedef float v2f __attribute__((ext_vector_type(2)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = p.W, H = p.H;
     const int x0 = blockIdx.x * PE_TX;
@@ -382,21 +388,21 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
 
     for (int yc = y_begin; yc < y_end; yc += PE_CH) {
         // ---- vertical pass ----
+        // per tap pair: (a+b, b-a) in one packed add, (t0,t2) += (g,xxg)*(a+b) in one packed fma, t1 in a scalar fma:
+        // 3 VALU instructions instead of 5, every lane-operation identical to the scalar form (same roundings)
         if (tid < PE_VW) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                float t0 = s[i + PE_N] * p.g[0], t1 = 0.f, t2 = 0.f;
+                v2f t02 = {s[i + PE_N] * p.g[0], 0.f};
+                float t1 = 0.f;
 #pragma unroll
                 for (int k = 1; k <= PE_N; k++) {
-                    float a = s[i + PE_N - k], b = s[i + PE_N + k];
-                    float pp = a + b;
-                    t0 = fmaf(p.g[k], pp, t0);
-                    t1 = fmaf(p.xg[k], b - a, t1);
-                    t2 = fmaf(p.xxg[k], pp, t2);
+                    const float a = s[i + PE_N - k], b = s[i + PE_N + k];
+                    const v2f pd = (v2f){b, b} + (v2f){a, -a};                     // (a + b, b - a)
+                    t02 = __builtin_elementwise_fma((v2f){p.g[k], p.xxg[k]}, (v2f){pd.x, pd.x}, t02);
+                    t1 = fmaf(p.xg[k], pd.y, t1);
                 }
-                t[0][i][tid] = t0;
-                t[1][i][tid] = t1;
-                t[2][i][tid] = t2;
+                t4[i][tid & 3][tid >> 2] = make_float4(t02.x, t1, t02.y, t1);
             }
         }
         __syncthreads();
@@ -411,15 +417,12 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
             if (y >= y_end) break;
             const int xo = x0 + 4 * lane;
             if (lane < PE_TX / 4 && xo < W) {
-                float a0[16], a1[16], a2[16];
+                v2f A[14], Q[14];          // (t0, t1) and (t2, t1) of strip pixels 4*lane .. 4*lane + 13
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 v0 = lds_read4(&t[0][rr][4 * lane + 4 * q]);
-                    const float4 v1 = lds_read4(&t[1][rr][4 * lane + 4 * q]);
-                    const float4 v2 = lds_read4(&t[2][rr][4 * lane + 4 * q]);
-                    a0[4 * q] = v0.x; a0[4 * q + 1] = v0.y; a0[4 * q + 2] = v0.z; a0[4 * q + 3] = v0.w;
-                    a1[4 * q] = v1.x; a1[4 * q + 1] = v1.y; a1[4 * q + 2] = v1.z; a1[4 * q + 3] = v1.w;
-                    a2[4 * q] = v2.x; a2[4 * q + 1] = v2.y; a2[4 * q + 2] = v2.z; a2[4 * q + 3] = v2.w;
+                for (int j = 0; j < 14; j++) {
+                    const float4 v = lds_read4(reinterpret_cast<const float *>(&t4[rr][j & 3][lane + (j >> 2)]));
+                    A[j] = (v2f){v.x, v.y};
+                    Q[j] = (v2f){v.z, v.w};
                 }
                 float r0[4], r1[4], r2[4], r3[4], r4[4];
 #pragma unroll
@@ -431,18 +434,21 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
                     // f32 FMA accumulation costs <= ~3 ulp per sum; measured effect on the flow vs the oracle:
                     // 4.7e-7 relative / 1.1e-4 px worst case incl. flat-bright and half-black frames (bar 1e-4 / 1e-3),
                     // the same as with f64 accumulators, for 40 % less time in this VALU-bound pass.
-                    float b1 = a0[c] * p.g[0], b4 = 0.f, b5 = a2[c] * p.g[0];
-                    float b2 = 0.f, b3 = a1[c] * p.g[0], b6 = 0.f;
+                    // packed over PAIRS OF SUMS (not pairs of pixels, whose operands would straddle register pairs):
+                    // per tap pair 3 packed adds + 3 packed fmas instead of 5 + 6 scalar ones
+                    v2f b14 = {A[c].x * p.g[0], 0.f};                    // (b1, b4)
+                    v2f b26 = {0.f, 0.f};                                // (b2, b6)
+                    v2f b53 = Q[c] * (v2f){p.g[0], p.g[0]};              // (b5, b3)
 #pragma unroll
                     for (int k = 1; k <= PE_N; k++) {
-                        const float tg = a0[c + k] + a0[c - k];
-                        b1 = fmaf(tg, p.g[k], b1);
-                        b4 = fmaf(tg, p.xxg[k], b4);
-                        b2 = fmaf(a0[c + k] - a0[c - k], p.xg[k], b2);
-                        b3 = fmaf(a1[c + k] + a1[c - k], p.g[k], b3);
-                        b6 = fmaf(a1[c + k] - a1[c - k], p.xg[k], b6);
-                        b5 = fmaf(a2[c + k] + a2[c - k], p.g[k], b5);
+                        const v2f sm = A[c + k] + A[c - k];              // (t0 sum, -)
+                        const v2f df = A[c + k] - A[c - k];              // (t0 diff, t1 diff)
+                        const v2f sq = Q[c + k] + Q[c - k];              // (t2 sum, t1 sum)
+                        b14 = __builtin_elementwise_fma((v2f){sm.x, sm.x}, (v2f){p.g[k], p.xxg[k]}, b14);
+                        b26 = __builtin_elementwise_fma(df, (v2f){p.xg[k], p.xg[k]}, b26);
+                        b53 = __builtin_elementwise_fma(sq, (v2f){p.g[k], p.g[k]}, b53);
                     }
+                    const float b1 = b14.x, b4 = b14.y, b2 = b26.x, b6 = b26.y, b5 = b53.x, b3 = b53.y;
                     r1[o] = b2 * (float)p.ig11;
                     r0[o] = b3 * (float)p.ig11;
                     r3[o] = (float)((double)b1 * p.ig03 + (double)b4 * p.ig33);
@@ -498,10 +504,12 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
 
 int polyexp_default_rows(int W, int H, int nimg)
 {
-    // 64-row strips amortise the 10-row window warm-up (1.16x input reads); shrink them only when the
-    // launch would not give every CU a few work-groups
+    // 16-row strips: the 10-row window warm-up re-reads input rows that the strip above is reading at about the same
+    // time (L2 hits), and the shorter strips keep more independent work-groups in flight -- measured 4.61 TB/s against
+    // 4.38 (64 rows) .. 4.53 (32-48 rows) on 64 1080p images.  Shrink further only when the launch would not give
+    // every CU a few work-groups.
     int tiles_x = cdiv(W, PE_TX);
-    int rows = 64;
+    int rows = 16;
     while (rows > PE_CH && (int64_t)tiles_x * cdiv(H, rows) * nimg < 1024) rows >>= 1;
     return rows;
 }
