@@ -550,7 +550,9 @@ __device__ __forceinline__ void um_load(const float *__restrict__ R0, const floa
                                         int W, int H, int x, int y, float2 fl, UmIn &u)
 {
 #pragma clang fp contract(off)
-    const size_t idx = (size_t)y * W + x;
+    // 32-bit BYTE offsets from the (uniform) frame base: global_load with an SGPR base and a 32-bit VGPR offset
+    // instead of a 64-bit address per lane.  The launchers check 20*W*H < 2^32.
+    const unsigned idx = (unsigned)y * (unsigned)W + (unsigned)x;
     float fx = (float)x + fl.x, fy = (float)y + fl.y;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     u.fx = fx - (float)x1;
@@ -560,13 +562,14 @@ __device__ __forceinline__ void um_load(const float *__restrict__ R0, const floa
     // bilinear taps of R1 are 40 contiguous bytes each.  dword-aligned vector loads (global_load_dwordx4/x2).
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    const float *q = R0 + idx * 5;
+    const float *q = reinterpret_cast<const float *>(reinterpret_cast<const char *>(R0) + idx * 20u);
     const f4u q0 = *reinterpret_cast<const f4u *>(q);
     u.r0[0] = q0.x; u.r0[1] = q0.y; u.r0[2] = q0.z; u.r0[3] = q0.w; u.r0[4] = q[4];
-    const float *p = R1 + (u.inr ? ((size_t)y1 * W + x1) * 5 : 0);
+    const unsigned o1 = u.inr ? ((unsigned)y1 * (unsigned)W + (unsigned)x1) * 20u : 0u;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
-        const float *pr = p + (size_t)rr * W * 5;
+        const float *pr = reinterpret_cast<const float *>(reinterpret_cast<const char *>(R1) +
+                                                          (o1 + (unsigned)rr * (unsigned)W * 20u));
         const f4u a = *reinterpret_cast<const f4u *>(pr), b = *reinterpret_cast<const f4u *>(pr + 4);
         const f2u c2 = *reinterpret_cast<const f2u *>(pr + 8);
         u.g[2 * rr][0] = a.x; u.g[2 * rr][1] = a.y; u.g[2 * rr][2] = a.z; u.g[2 * rr][3] = a.w; u.g[2 * rr][4] = b.x;
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 int launch_update_matrices(const float *R0, const float *R1, size_t pair_stride_R,
                            const float *flow, float *M, int npair, int W, int H, hipStream_t s)
 {
+    if ((int64_t)W * H * 5 >= (1ll << 30)) { set_error("frame too large for 32-bit R offsets (%dx%d)", W, H); return OFC_EUNSUPPORTED; }
     dim3 grid(cdiv(W, 256), H, npair);
     hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, s, R0, R1, pair_stride_R, flow, M, W, H);
     OFC_HIP(hipGetLastError());
@@ -878,7 +882,6 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
-    float last[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- warm-up: rows y_begin-M .. y_begin+M (replicate-clamped), two at a time ----
 #pragma unroll
@@ -903,7 +906,6 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                 for (int c = 0; c < 5; c++) {
                     ring[(j2 + q + 16) & 15][c] = m[c];
                     v[c] += (double)m[c];
-                    last[c] = m[c];
                 }
             }
         }
@@ -926,17 +928,10 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     for (int q = 0; q < BS_ROWS; q++)            // the gathers of all four rows in flight together
                         um_load(R0, R1, plane, W, H, xc, min(yc + q + 1 + M, H - 1), fl[q], u[q]);
 #pragma unroll
-                    for (int r = 0; r < BS_ROWS; r++) {
-                        const int e = yc + r + 1 + M;
-                        if (e <= H - 1) {
-                            um_math(u[r], W, H, xc, e, fl[r], mi[r]);
-#pragma unroll
-                            for (int c = 0; c < 5; c++) last[c] = mi[r][c];
-                        } else {                                // replicate the last image row
-#pragma unroll
-                            for (int c = 0; c < 5; c++) mi[r][c] = last[c];
-                        }
-                    }
+                    // rows below the image replicate row H-1: the loads above were clamped to it, and the same inputs give
+                    // the same matrix entries again (no carried copy, no select)
+                    for (int r = 0; r < BS_ROWS; r++)
+                        um_math(u[r], W, H, xc, min(yc + r + 1 + M, H - 1), fl[r], mi[r]);
                 }
                 // the barrier that protects `vs` from the previous step's readers sits HERE, after this step's loads and
                 // matrix arithmetic: a wave that finished its horizontal pass early starts its gathers without waiting
@@ -1021,6 +1016,7 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
                      float mul)
 {
     if (winsize > 15) { set_error("fused iteration supports winsize <= 15 (ring of 16 rows)"); return OFC_EUNSUPPORTED; }
+    if ((int64_t)W * H * 5 >= (1ll << 30)) { set_error("frame too large for 32-bit R offsets (%dx%d)", W, H); return OFC_EUNSUPPORTED; }
     const int rows_per_block = flow_iter_rows(W, H, npair, winsize);
     UpsArgs u;
     u.src = coarse; u.sw = sw; u.sh = sh; u.mul = mul;

@@ -8,30 +8,13 @@
 
 namespace ofc {
 
-static double np_sum_small(const double *a, int n)
-{
-    if (n < 8) {
-        double r = 0;
-        for (int i = 0; i < n; i++) r += a[i];
-        return r;
-    }
-    double r[8];
-    int i;
-    for (i = 0; i < 8; i++) r[i] = a[i];
-    for (i = 8; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; j++) r[j] += a[i + j];
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += a[i];
-    return res;
-}
-
 static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC_F32 ? 4 : 8); }
 
 // Per-device scratch, created once and reused by every fit: creating/destroying a HIP stream (1.5-6 ms) and
 // pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
     DevBuf state, partial, tot, excl, far, labels;
-    LloydStatus *status = nullptr;       // pinned, device-visible
+    LloydStatus *status = nullptr;       // pinned, device-visible; one slot per iteration of a window
     LloydStatus *status_dev = nullptr;
     hipStream_t stream = nullptr;
     bool ready = false;
@@ -45,7 +28,7 @@ struct LloydScratch {
         OFC_TRY(tot.alloc(sizeof(double) * (NVMAX + 8)));
         OFC_TRY(excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
         OFC_TRY(far.alloc(sizeof(double) * 2 * 2048));
-        OFC_HIP(hipHostMalloc((void **)&status, sizeof(LloydStatus), hipHostMallocMapped));
+        OFC_HIP(hipHostMalloc((void **)&status, sizeof(LloydStatus) * LLOYD_WINDOW, hipHostMallocMapped));
         OFC_HIP(hipHostGetDevicePointer((void **)&status_dev, status, 0));
         ready = true;
         return OFC_OK;
@@ -173,7 +156,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     double *tot = sc.tot.as<double>();
 
     // ---- column mean (X.mean(axis=0), _kmeans.py:1478-1484) and tol (_tolerance, :279-287) ----
-    double hbuf[LLOYD_DMAX + 1], mean_h[LLOYD_DMAX], var_h[LLOYD_DMAX];
+    double hbuf[LLOYD_DMAX + 1], mean_h[LLOYD_DMAX];
     OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 0, sc.partial.as<double>(), nblocks, s));
     OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
     double nloc = (double)N;
@@ -188,7 +171,6 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     }
     for (int f = 0; f < d; f++) mean_h[f] = hbuf[f] / Ng;
     OFC_HIP(hipMemcpyAsync(st->mean, mean_h, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    double tol = 0;      // mean(var) * tol_rel: the column sums of (x-mean)^2 ride along with the first iteration
 
     // ---- centred init ----
     double c0[LLOYD_KMAX * LLOYD_DMAX];
@@ -204,33 +186,48 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     // iteration that meets an empty cluster: relocation needs the labels, and a relocated centre breaks the
     // equal-labels => zero-shift argument.  That iteration itself cannot be a strict stop: equal labels would mean the
     // previous iteration had the same empty cluster.
-    bool strict = false, labelled = false;
+    //
+    // The convergence test runs on the device (k_lloyd_update) and the host enqueues LLOYD_WINDOW iterations per
+    // synchronisation: an iteration behind the one that converged (or met an empty cluster) finds st->halt set and
+    // does nothing.  One host round trip per window instead of one per iteration (18 us each -- a tenth of an
+    // iteration on a 1/8 shard); every rank takes the same decisions because they derive from all-reduced totals.
+    bool strict = false, labelled = false, stop = false;
     int it = 0;
-    for (it = 0; it < max_iter; it++) {
-        OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, labelled ? 1 : 3,
-                                    it == 0, s));
-        OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s));
-        OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
-        OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, sc.status_dev, s));
+    const int *halt = &st->halt;
+    while (it < max_iter && !stop) {
+        const int nwin = std::min(LLOYD_WINDOW, max_iter - it);
+        for (int w = 0; w < nwin; w++) sc.status[w].valid = 0;
+        for (int w = 0; w < nwin; w++) {
+            OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
+                                        labelled ? 1 : 3, it + w == 0, s));
+            OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s, halt));
+            OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
+            OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, labelled, it + w == 0, Ng, tol_rel, sc.status_dev + w, s));
+        }
         OFC_HIP(hipStreamSynchronize(s));
-        const bool was_labelled = labelled;
-        if (sc.status->n_empty > 0) {
-            if (!labelled) {       // materialise this iteration's labels (st->centers is still the E-step's input)
-                OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, s));
-                labelled = true;
+        int done = nwin;                      // iterations of this window that really ran
+        for (int w = 0; w < nwin; w++) {
+            LloydStatus &S = sc.status[w];
+            if (!S.valid) { set_error("internal: Lloyd iteration %d did not run", it + w); return OFC_EHIP; }
+            if (S.n_empty > 0) {              // the device stalled here; iterations w+1.. of the window were no-ops
+                const bool was_labelled = labelled;
+                if (!labelled) {   // materialise this iteration's labels (st->centers is still the E-step's input)
+                    OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, s));
+                    labelled = true;
+                }
+                OFC_TRY(relocate_empty(sc, X, dtype, N, d, k, kmax, nblocks, labels_dev, mean_h));
+                S.valid = 0;
+                OFC_TRY(launch_lloyd_update(st, tot, k, d, 1, was_labelled, it + w == 0, Ng, tol_rel, sc.status_dev + w, s));
+                OFC_HIP(hipStreamSynchronize(s));
+                done = w + 1;
+                if (S.converged) { strict = S.strict != 0; it += w; stop = true; }
+                break;
             }
-            OFC_TRY(relocate_empty(sc, X, dtype, N, d, k, kmax, nblocks, labels_dev, mean_h));
-            OFC_TRY(launch_lloyd_update(st, tot, k, d, 1, sc.status_dev, s));
-            OFC_HIP(hipStreamSynchronize(s));
+            if (S.converged) { strict = S.strict != 0; it += w; stop = true; break; }
         }
-        if (it == 0 && tol_rel != 0) {
-            for (int f = 0; f < d; f++) var_h[f] = sc.status->sqsum[f] / Ng;
-            tol = np_sum_small(var_h, d) / (double)d * tol_rel;
-        }
-        if (was_labelled && sc.status->n_changed == 0.0) { strict = true; break; }
-        if (sc.status->shift_tot <= tol) break;
+        if (!stop) it += done;
     }
-    if (it == max_iter) it = max_iter - 1;
+    if (!stop) it = max_iter - 1;        // ran out of iterations: n_iter = max_iter
     // ---- final E-step (only when not strictly converged) and inertia: one sweep ----
     if (!strict)
         OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 2, 0, s));

@@ -13,14 +13,20 @@ struct LloydState {
     double centers[LLOYD_KMAX * LLOYD_DMAX];      // current (old) centres, row-major k x d
     double centers_new[LLOYD_KMAX * LLOYD_DMAX];
     double cn[LLOYD_KMAX];                        // |c_j|^2 (FMA chain)
+    double tol;                                   // sklearn's tol (mean column variance * tol_rel), set by iteration 0
+    int halt;                                     // set by k_lloyd_update on convergence / empty cluster: the iterations
+    int pad;                                      // that were enqueued speculatively behind it become no-ops
 };
 
-// written by k_lloyd_update into pinned host memory once per iteration
+// written by k_lloyd_update into pinned host memory once per iteration (one slot per iteration of a window)
 struct LloydStatus {
     double n_changed;
     double shift_tot;
     int n_empty;
-    int pad;
+    int valid;        // the iteration ran (0: it was a no-op behind a halt)
+    int converged;    // strict or tol stop reached in this iteration
+    int strict;       // ... by labels == labels_old
+    double tol;
     double counts[LLOYD_KMAX];
     double sqsum[LLOYD_DMAX];     // sum (x-mean)^2 per column (first iteration only)
 };
@@ -28,15 +34,20 @@ struct LloydStatus {
 int lloyd_kmax(int k);
 int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const double *mean, int pass,
                           double *partial, int nblocks, hipStream_t s);
-int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s);
+// halt != nullptr: skip when *halt != 0 (device flag)
+int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s,
+                          const int *halt = nullptr);
 // mode 0: labels only; 1: labels + M-step record (+ column sums of (x-mean)^2 when first != 0); 2: labels + inertia;
 // 3: M-step record only (labels untouched, n_changed = 0)
 // record = [kmax*d sums][kmax counts][n_changed][LLOYD_DMAX squared sums]
 int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
                         uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s);
 inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + 1 + LLOYD_DMAX; }
-int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc,
-                        LloydStatus *status, hipStream_t s);
+// labelled: tot's n_changed slot is meaningful (mode 1); first: iteration 0, which also fixes st->tol from the
+// column sums of (x-mean)^2 in tot, n_total samples and tol_rel
+int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
+                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s);
+constexpr int LLOYD_WINDOW = 4;     // iterations enqueued per host synchronisation
 int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s);
 int launch_lloyd_inertia(const void *X, int dtype, int64_t N, int d, const LloydState *st,
                          const uint8_t *labels, double *partial, int nblocks, hipStream_t s);

@@ -129,9 +129,10 @@ __global__ __launch_bounds__(256) void k_colstats(const T *__restrict__ X, int64
 // fixed-order sum of per-block records: out[i] = sum_b partial[b][i].  1024 threads: component i is
 // summed by nstripes = 1024/nv threads over interleaved record subsets, then folded in stripe order.
 __global__ __launch_bounds__(1024) void k_reduce_records(const double *__restrict__ partial, int nblocks,
-                                                         int nv, double *__restrict__ out)
+                                                         int nv, double *__restrict__ out, const int *halt)
 {
     __shared__ double lds[1024];
+    if (halt && *halt) return;
     const int nstripes = 1024 / nv;
     const int i = threadIdx.x % nv, st = threadIdx.x / nv;
     double a = 0;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
                                                       double *__restrict__ partial, int first)
 {
     constexpr bool ACCUM = (MODE == 1 || MODE == 3), LABELS = (MODE != 3);
+    if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
     constexpr int NV = KMAX * D + KMAX + 1 + LLOYD_DMAX;     // [sums][counts][changed][sum (x-mean)^2 per column]
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                       // [k*D][256]
@@ -315,6 +317,24 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     }
 }
 
+// numpy's pairwise sum for n <= 128 (sequential below 8 elements, 8 lanes above)
+__device__ inline double np_sum_small_dev(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
 // ------------------------------------------------------------------------------------------------
 // M-step finish on one lane: (optional relocation is done by the host before this), average, shift,
 // convergence inputs.  tot: [KMAX*D sums][KMAX counts][changed] (already all-reduced if distributed).
@@ -322,9 +342,11 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
 // still-empty clusters.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, int k, int d, int kmax,
-                               int after_reloc, LloydStatus *status /* pinned host */)
+                               int after_reloc, int labelled, int first, double n_total, double tol_rel,
+                               LloydStatus *status /* pinned host */)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->halt && !after_reloc) return;           // no-op behind a converged / stalled iteration
     double *cnew = st->centers_new;
     const double *w = tot + kmax * d;
     int amax = 0, n_empty = 0;
@@ -334,11 +356,16 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
     }
     if (n_empty > 0 && !after_reloc) {
         // _relocate_empty_clusters_dense needs a pass over the data: hand back to the host, which
-        // patches `tot` and calls again with after_reloc = 1.  Nothing is modified here.
+        // patches `tot` and calls again with after_reloc = 1.  Nothing is modified here except the halt flag.
+        st->halt = 1;
         status->n_empty = n_empty;
         status->n_changed = tot[kmax * d + kmax];
         status->shift_tot = -1;
+        status->converged = 0;
+        status->strict = 0;
         for (int j = 0; j < k; j++) status->counts[j] = w[j];
+        __threadfence_system();
+        status->valid = 1;
         return;
     }
     for (int j = 0; j < k; j++)
@@ -352,7 +379,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
         }
     }
     // shift (4-way grouped squared distance, then sqrt, squared again and summed numpy-style)
-    double sh2[256];
+    double sh2[LLOYD_KMAX];
     for (int j = 0; j < k; j++) {
         const double *a = cnew + j * d, *b = st->centers + j * d;
         double r = 0;
@@ -364,19 +391,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
         const double s = sqrt(r);
         sh2[j] = s * s;
     }
-    double tot_shift;
-    if (k < 8) {
-        tot_shift = 0;
-        for (int j = 0; j < k; j++) tot_shift += sh2[j];
-    } else {   // numpy pairwise sum, n <= 128 block
-        double r[8];
-        int i;
-        for (i = 0; i < 8; i++) r[i] = sh2[i];
-        for (i = 8; i < k - (k % 8); i += 8)
-            for (int j = 0; j < 8; j++) r[j] += sh2[i + j];
-        tot_shift = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < k; i++) tot_shift += sh2[i];
-    }
+    const double tot_shift = np_sum_small_dev(sh2, k);
     // swap: centers <- centers_new, new |c|^2
     for (int j = 0; j < k; j++) {
         double acc = cnew[j * d] * cnew[j * d];
@@ -384,11 +399,27 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
         st->cn[j] = acc;
         for (int f = 0; f < d; f++) st->centers[j * d + f] = cnew[j * d + f];
     }
-    status->n_changed = tot[kmax * d + kmax];
+    // tol = mean(X.var(axis=0)) * tol_rel (_tolerance, _kmeans.py:279-287): the column sums of (x-mean)^2 ride along
+    // with iteration 0's record
+    if (first) {
+        double var[LLOYD_DMAX];
+        for (int f = 0; f < d; f++) var[f] = tot[kmax * d + kmax + 1 + f] / n_total;
+        st->tol = tol_rel != 0 ? np_sum_small_dev(var, d) / (double)d * tol_rel : 0.0;
+    }
+    const double n_changed = tot[kmax * d + kmax];
+    const int strict = labelled && n_changed == 0.0;
+    const int converged = strict || tot_shift <= st->tol;
+    st->halt = converged;
+    status->n_changed = n_changed;
     for (int f = 0; f < d; f++) status->sqsum[f] = tot[kmax * d + kmax + 1 + f];
     status->shift_tot = tot_shift;
+    status->tol = st->tol;
     status->n_empty = 0;
+    status->converged = converged;
+    status->strict = strict;
     for (int j = 0; j < k; j++) status->counts[j] = w[j];
+    __threadfence_system();
+    status->valid = 1;
 }
 
 // sets centres (centred) + |c|^2 from host-provided values
@@ -567,18 +598,19 @@ int launch_lloyd_colstats(const void *X, int dtype, int64_t N, int d, const doub
     return rc;
 }
 
-int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s)
+int launch_reduce_records(const double *partial, int nblocks, int nv, double *out, hipStream_t s, const int *halt)
 {
     if (nv > 256) { set_error("record too long"); return OFC_EINVAL; }
-    hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(1024), 0, s, partial, nblocks, nv, out);
+    hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(1024), 0, s, partial, nblocks, nv, out, halt);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }
 
-int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc,
-                        LloydStatus *status, hipStream_t s)
+int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
+                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lloyd_update, dim3(1), dim3(64), 0, s, st, tot, k, d, lloyd_kmax(k), after_reloc, status);
+    hipLaunchKernelGGL(k_lloyd_update, dim3(1), dim3(64), 0, s, st, tot, k, d, lloyd_kmax(k), after_reloc, labelled,
+                       first, n_total, tol_rel, status);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }
