@@ -164,3 +164,14 @@ def imread_bgr(path):
         return cv2.imread(path)
     from PIL import Image
     return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[..., ::-1])
+
+
+def imwrite_bgr(path, img):
+    """cv2.imwrite equivalent for 8-bit BGR (or single-channel) images; PNG is lossless either way"""
+    if _have_cv2():
+        import cv2
+        return bool(cv2.imwrite(path, img))
+    from PIL import Image
+    img = np.ascontiguousarray(img, np.uint8)
+    Image.fromarray(img[..., ::-1] if img.ndim == 3 else img).save(path)
+    return True

@@ -219,3 +219,48 @@ def test_streaming_ingest_cell_averaged_flow_and_kmeans():
     km = KMeans(n_clusters=8, init=C0).fit(X)
     oc, ol, _, on = O.kmeans_fit(X, C0)
     assert km.n_iter_ == on and np.array_equal(km.labels_, ol) and np.abs(km.cluster_centers_ - oc).max() <= 1e-9
+
+
+def test_draw_grids_stage_writes_cells_csv_and_video_and_feeds_color_kmeans_change(tmp_path, monkeypatch):
+    """the reference's documented two-step pipeline (drawGridsAndOutputCSVChange.py:261-262): stage 1 writes
+    OutImgs/<video>/<frame>/<cell>.png + rgb_values.csv + <video>_output.mp4, stage 2 (color_kmeansChange -d) clusters
+    the PNG cells.  Stage 1 is checked against the oracle pipeline, stage 2 against KmeanGrids' fused form."""
+    from opticalflowclustering_amd import color_kmeansChange, drawGridsAndOutputCSV
+    from opticalflowclustering_amd.frameio import imread_bgr
+    v = make_video(W=700, H=420, T=3)
+    src = str(tmp_path / "clip.npy")
+    np.save(src, v)
+    monkeypatch.chdir(tmp_path)
+    drawGridsAndOutputCSV.main(["--noyolo", "--nocontour", "--path", src])
+    rows = list(csv.reader(open(tmp_path / "rgb_values.csv")))
+    assert rows[0] == [f"cell_{i}" for i in range(350)] and len(rows) == 3
+    for t in (1, 2):
+        (vis, _), _ = oracle_vis(v[t - 1], v[t])
+        _, hsv = O.grid_cell_means(vis)
+        got = [float(x) for x in rows[t]]
+        assert all(("." in x) for x in rows[t])                       # str(float): "60.0", as the recorded CSVs
+        assert sum(g != float(w) for g, w in zip(got, hsv[:, 0])) <= 3    # truncation-boundary pixels, see above
+        for c in (0, 26, 349):
+            cell = imread_bgr(str(tmp_path / "OutImgs" / "clip" / str(t + 1) / f"{c + 1}.png"))
+            want = O.extract_cell(vis, c)
+            assert cell.shape == want.shape and (cell == want).mean() >= 0.995
+            if c == 26:
+                assert (cell[0] == 255).all() and (cell[:, 0] == 255).all()
+    data = open(src + "_output.mp4", "rb").read()
+    assert data[:4] == b"RIFF" and data.count(b"00dc") >= 2
+    # stage 2 on the PNG cells.  color_kmeansChange reads each PNG and converts BGR->RGB before clustering, then treats
+    # the centre as BGR again (the reference's RGB-order quirk, KAT-B), so its hue differs from KmeanGrids' by design:
+    # the check is the oracle on the same files with the same quirk.
+    color_kmeansChange.main(["-d", "OutImgs/clip", "-c", "1", "-f", "x.csv"])
+    got = {}
+    for name, _, _, hue in csv.reader(open(tmp_path / "x.csv")):
+        frame_no, cell = name.replace(".png", "").split("/")
+        got.setdefault(int(frame_no), {})[int(cell)] = int(hue)
+    assert sorted(got) == [2, 3] and all(len(got[f]) == 350 for f in got)
+    for frame_no in (2, 3):
+        for c in range(1, 351, 7):
+            rgb = imread_bgr(str(tmp_path / "OutImgs" / "clip" / str(frame_no) / f"{c}.png"))[..., ::-1]
+            X = O.preprocess_rgba(np.ascontiguousarray(rgb)).reshape(-1, 4)
+            cen, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
+            want = int(O.bgr2hsv(np.rint(cen[0])[:3].astype(np.uint8).reshape(1, 1, 3))[0, 0, 0])
+            assert got[frame_no][c] == want, (frame_no, c)

@@ -139,3 +139,34 @@ def test_seeded_rows_init_is_deterministic_and_distinct():
     X = np.random.default_rng(1).integers(0, 4, (500, 4), dtype=np.uint8)
     a, b = seeded_rows_init(X, 5), seeded_rows_init(X, 5)
     assert np.array_equal(a, b) and len(np.unique(a, axis=0)) == 5
+
+
+def test_draw_grids_overlay_formats(tmp_path, monkeypatch):
+    """drawGridsAndOutputCSVChange.overlayGridAndComputeAvgColor: CSV wire format (float hue strings, header only for
+    framNum <= 2 which also truncates), cell PNGs = views incl. the neighbours' grid lines, captions inside the frame.
+    The device call is replaced by the oracle here (CPU suite)."""
+    from oracle import oracle as O
+    from opticalflowclustering_amd import drawGridsAndOutputCSVChange as D
+    from opticalflowclustering_amd.frameio import imread_bgr
+    monkeypatch.setattr(D, "grid_cell_means", lambda frame, rows, cols, device=0: O.grid_cell_means(frame, rows, cols))
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(4)
+    frame = rng.integers(0, 200, (140, 250, 3), dtype=np.uint8)
+    f0 = frame.copy()
+    open("rgb_values.csv", "w").write("stale\n")
+    _, hues = D.overlayGridAndComputeAvgColor(2, frame, D.GRID_PARAMS, "rgb_values.csv", "some/dir/clip.mp4")
+    D.overlayGridAndComputeAvgColor(3, f0.copy(), D.GRID_PARAMS, "rgb_values.csv", "some/dir/clip.mp4")
+    lines = open("rgb_values.csv").read().splitlines()
+    assert len(lines) == 3 and lines[0].split(",")[:2] == ["cell_0", "cell_1"] and lines[1] == lines[2]
+    _, oh = O.grid_cell_means(f0)
+    assert lines[1].split(",") == [str(float(h)) for h in oh[:, 0]] and hues == [float(h) for h in oh[:, 0]]
+    cell = imread_bgr("OutImgs/clip/2/27.png")                       # row 1, col 1
+    assert np.array_equal(cell, O.extract_cell(f0, 26, 14, 25))
+    assert len(os.listdir("OutImgs/clip/3")) == 350
+    assert (frame[0, :250] == 255).all() and (frame[:140, 10] == 255).all()      # grid lines
+    tw, th = D.get_text_size("(255, 255, 255)")
+    canvas = np.zeros((20, 120, 3), np.uint8)
+    D.put_text(canvas, "(255, 255, 255)", (3, 15))
+    ys, xs = np.nonzero(canvas[..., 0])
+    assert xs.min() >= 3 and xs.max() < 3 + tw and ys.max() <= 15 and ys.min() >= 15 - th + 1
+    assert set("0123456789(), ") <= set(D._FONT)
