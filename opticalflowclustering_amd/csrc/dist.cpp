@@ -69,7 +69,7 @@ int dist_world() { return g_world; }
 
 int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s)
 {
-    if (!g_comm || g_world <= 1) return OFC_OK;
+    if (!g_comm) return OFC_OK;      // a world-1 communicator (OFC_FORCE_DIST rehearsal) still issues the collective
     const int nop = op == DIST_SUM ? NCCL_SUM : (op == DIST_MAX ? NCCL_MAX : NCCL_MIN);
     OFC_NCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, NCCL_FLOAT64, nop, g_comm, s));
     return OFC_OK;
