@@ -110,6 +110,9 @@ int ofc_level_image(int device, const uint8_t *gray, int W, int H, const ofc_fb_
                     float *out, int *w_out, int *h_out);
 /* FarnebackPolyExp: f32 HxW -> f32 HxWx5 {y-lin, x-lin, y^2, x^2, xy} */
 int ofc_polyexp(int device, const float *img, int W, int H, int n, double sigma, float *R5);
+/* the same for pyramid level 0 straight from the u8 frame (level-0 blur fused in; what ofc_flow_* runs at level 0):
+ * must equal ofc_level_image(k=0) followed by ofc_polyexp bit for bit.  OFC_EUNSUPPORTED when W < 4 or H < 2 */
+int ofc_polyexp_u8(int device, const uint8_t *gray, int W, int H, int n, double sigma, float *R5);
 /* FarnebackUpdateMatrices: R0,R1 HxWx5, flow HxWx2 -> M HxWx5 */
 int ofc_update_matrices(int device, const float *R0, const float *R1, const float *flow, int W,
                         int H, float *M);

@@ -58,6 +58,7 @@ _PROTOS = {
     "ofc_flow_last_vis_dev": ([_vp, C.POINTER(_vp)], _i),
     "ofc_level_image": ([_i, _vp, _i, _i, C.POINTER(FbParams), _i, _vp, _ip, _ip], _i),
     "ofc_polyexp": ([_i, _vp, _i, _i, _i, _d, _vp], _i),
+    "ofc_polyexp_u8": ([_i, _vp, _i, _i, _i, _d, _vp], _i),
     "ofc_update_matrices": ([_i, _vp, _vp, _vp, _i, _i, _vp], _i),
     "ofc_box_solve": ([_i, _vp, _i, _i, _i, _vp], _i),
     "ofc_flow_resize": ([_i, _vp, _i, _i, _i, _i, _f, _vp], _i),

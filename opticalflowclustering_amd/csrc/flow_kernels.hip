@@ -355,9 +355,13 @@ struct PolyArgs {
     double ig11, ig03, ig33, ig55;
 };
 
-// TAG only gives the bench hook's launches their own symbol in rocprof's kernel statistics
-template <int TAG>
-__global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I, float *__restrict__ R,
+// TAG only gives the bench hook's launches their own symbol in rocprof's kernel statistics.
+// U8IN: the pyramid's level 0 (3x3 [1/4 1/2 1/4] blur of the u8 frame, REFLECT_101, no decimation) is evaluated on the
+// fly from the frame instead of being read back as an f32 image: 1 B/px read instead of 4, and the level-0 image
+// kernel with its 5 B/px disappears.  Every intermediate value of that blur is a multiple of 1/16 below 256, exactly
+// representable in f32 whatever the evaluation order, so the result is bit-identical to k_level0 + this kernel.
+template <int TAG, bool U8IN>
+__global__ __launch_bounds__(256, 3) void k_polyexp(const void *__restrict__ Iv, float *__restrict__ R,
                                                  PolyArgs p)
 {
     // vertical moments of the chunk, one float4 (t0, t1, t2, t1) per pixel: the horizontal pass consumes them as the
@@ -374,17 +378,50 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
     const int y_begin = blockIdx.y * p.rows_per_block;
     const int y_end = min(y_begin + p.rows_per_block, H);
     const size_t plane = (size_t)W * H;
-    const float *img = I + (size_t)blockIdx.z * plane;
+    const float *img = U8IN ? nullptr : reinterpret_cast<const float *>(Iv) + (size_t)blockIdx.z * plane;
+    const uint8_t *img8 = U8IN ? reinterpret_cast<const uint8_t *>(Iv) + (size_t)blockIdx.z * plane : nullptr;
     float *out = R + (size_t)blockIdx.z * 5 * plane;
     const int xc = min(max(x0 - PE_N + tid, 0), W - 1);   // this thread's (clamped) column
     const bool vec_ok = (W & 3) == 0;
 
+    // U8IN: one (unaligned) dword per frame row holds the three horizontal taps of this column: bytes
+    // reflect101(xc-1), xc, reflect101(xc+1) all lie in [base, base+3] for base = clamp(xc-1, 0, W-4)
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    const int base = U8IN ? min(max(xc - 1, 0), W - 4) : 0;
+    const int sh0 = U8IN ? 8 * (reflect101(xc - 1, W) - base) : 0, sh1 = U8IN ? 8 * (xc - base) : 0,
+              sh2 = U8IN ? 8 * (reflect101(xc + 1, W) - base) : 0;
+    auto hword = [&](int r) -> uint32_t { return *reinterpret_cast<const u32u *>(img8 + (size_t)r * W + base); };
+    auto hval = [&](uint32_t w) -> float {          // row-blurred sample (exact: a multiple of 1/4)
+        return 0.25f * (float)((w >> sh0) & 255u) + 0.5f * (float)((w >> sh1) & 255u) + 0.25f * (float)((w >> sh2) & 255u);
+    };
+    auto i0_any = [&](int r) -> float {             // level-0 image at (valid) row r, any position: 3 row loads
+        return 0.25f * hval(hword(reflect101(r - 1, H))) + 0.5f * hval(hword(r)) + 0.25f * hval(hword(reflect101(r + 1, H)));
+    };
+    // strips whose rows (incl. the +-1 blur rows) need neither clamping nor reflection share the row-blurred samples
+    // between consecutive level-0 rows: 20 + 8 per chunk dword loads per thread, the count of the f32 path
+    const bool interior = U8IN && y_begin >= PE_N + 1 && y_begin + p.rows_per_block + 2 * PE_N + 2 <= H - 1;
+
     // register window of this thread's column: rows yc-5 .. yc+12; slides down 8 rows per chunk, the 8 new
     // rows are requested right after the barrier so that their HBM latency hides under the horizontal pass
     float s[8 + 2 * PE_N], nxt[8];
+    uint32_t nxtw[8];
+    float hk0 = 0.f, hk1 = 0.f;                         // U8IN interior: row-blurred samples of window rows 18, 19
+    if (!U8IN) {
 #pragma unroll
-    for (int j = 0; j < 8 + 2 * PE_N; j++)
-        s[j] = img[(size_t)min(max(y_begin - PE_N + j, 0), H - 1) * W + xc];
+        for (int j = 0; j < 8 + 2 * PE_N; j++)
+            s[j] = img[(size_t)min(max(y_begin - PE_N + j, 0), H - 1) * W + xc];
+    } else if (interior) {
+        float hv[8 + 2 * PE_N + 2];
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * PE_N + 2; j++) hv[j] = hval(hword(y_begin - PE_N - 1 + j));
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * PE_N; j++) s[j] = 0.25f * hv[j] + 0.5f * hv[j + 1] + 0.25f * hv[j + 2];
+        hk0 = hv[8 + 2 * PE_N];
+        hk1 = hv[8 + 2 * PE_N + 1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * PE_N; j++) s[j] = i0_any(min(max(y_begin - PE_N + j, 0), H - 1));
+    }
 
     for (int yc = y_begin; yc < y_end; yc += PE_CH) {
         // ---- vertical pass ----
@@ -407,9 +444,17 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
         }
         __syncthreads();
         if (yc + PE_CH < y_end) {
+            if (!U8IN) {
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                nxt[j] = img[(size_t)min(yc + PE_CH + PE_N + j, H - 1) * W + xc];
+                for (int j = 0; j < 8; j++)
+                    nxt[j] = img[(size_t)min(yc + PE_CH + PE_N + j, H - 1) * W + xc];
+            } else if (interior) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) nxtw[j] = hword(yc + PE_CH + PE_N + 1 + j);   // frame rows yc+14 .. yc+21
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) nxt[j] = i0_any(min(yc + PE_CH + PE_N + j, H - 1));
+            }
         }
         // ---- horizontal pass ----
         for (int rr = wave; rr < PE_CH; rr += 4) {
@@ -496,8 +541,20 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const float *__restrict__ I,
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2 * PE_N; j++) s[j] = s[j + 8];
+        if (U8IN && interior) {
+            float hn[10];
+            hn[0] = hk0;
+            hn[1] = hk1;
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[2 * PE_N + j] = nxt[j];
+            for (int j = 0; j < 8; j++) hn[2 + j] = hval(nxtw[j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[2 * PE_N + j] = 0.25f * hn[j] + 0.5f * hn[j + 1] + 0.25f * hn[j + 2];
+            hk0 = hn[8];
+            hk1 = hn[9];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[2 * PE_N + j] = nxt[j];
+        }
     }
 }
 
@@ -514,18 +571,42 @@ int polyexp_default_rows(int W, int H, int nimg)
     return rows;
 }
 
-int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
-                   int rows_per_block, hipStream_t s, bool bench_tag)
+static void polyexp_args(PolyArgs &a, int W, int H, int nimg, const PolyConsts &c, int rows_per_block)
 {
-    PolyArgs a;
     a.W = W; a.H = H;
     for (int i = 0; i <= PE_N; i++) { a.g[i] = c.g[i]; a.xg[i] = c.xg[i]; a.xxg[i] = c.xxg[i]; }
     a.ig11 = c.ig11; a.ig03 = c.ig03; a.ig33 = c.ig33; a.ig55 = c.ig55;
     if (rows_per_block <= 0) rows_per_block = polyexp_default_rows(W, H, nimg);
     a.rows_per_block = cdiv(rows_per_block, PE_CH) * PE_CH;
+}
+
+// polyexp of pyramid level 0 straight from the u8 frames (see U8IN); the caller checks polyexp_u8_ok()
+bool polyexp_u8_ok(int W, int H, const LevelGeom &g)
+{
+    if (g.w != W || g.h != H || g.ksize != 3 || W < 4 || H < 2) return false;
+    float k[3];
+    gaussian_kernel(3, g.sigma, k);
+    return k[0] == 0.25f && k[1] == 0.5f && k[2] == 0.25f;
+}
+
+int launch_polyexp_u8(const uint8_t *frames, float *R, int nimg, int W, int H, const PolyConsts &c, hipStream_t s)
+{
+    PolyArgs a;
+    polyexp_args(a, W, H, nimg, c, 0);
     dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
-    if (bench_tag) hipLaunchKernelGGL(k_polyexp<1>, grid, dim3(256), 0, s, I, R, a);
-    else hipLaunchKernelGGL(k_polyexp<0>, grid, dim3(256), 0, s, I, R, a);
+    hipLaunchKernelGGL((k_polyexp<0, true>), grid, dim3(256), 0, s, frames, R, a);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
+                   int rows_per_block, hipStream_t s, bool bench_tag)
+{
+    PolyArgs a;
+    polyexp_args(a, W, H, nimg, c, rows_per_block);
+    dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
+    if (bench_tag) hipLaunchKernelGGL((k_polyexp<1, false>), grid, dim3(256), 0, s, I, R, a);
+    else hipLaunchKernelGGL((k_polyexp<0, false>), grid, dim3(256), 0, s, I, R, a);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

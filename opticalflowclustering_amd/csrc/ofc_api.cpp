@@ -223,6 +223,7 @@ struct ofc_flow {
     hipStream_t stream = nullptr;
     DevBuf I, R, M, flowA, flowB, flowC;   // scratch sized for level 0 and max_batch
     bool fused = true;              // update-matrices fused into the box/solve kernel (winsize <= 15)
+    bool fuse_level0 = true;        // polyexp of level 0 reads the u8 frames (no f32 level-0 image)
     DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
@@ -247,8 +248,12 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
         // dst and tmp, so the initial flow goes to whichever makes the last iteration write dst
         float *dst = (k == 0) ? flow_dev : (((f->levels - k) & 1) ? f->flowB.as<float>() : f->flowA.as<float>());
         float *tmp = f->flowC.as<float>();
-        OFC_TRY(launch_level_image(frames_dev, I, n_frames, W, H, g, s));
-        OFC_TRY(launch_polyexp(I, R, n_frames, g.w, g.h, f->pc, 0, s));
+        if (k == 0 && f->fuse_level0 && polyexp_u8_ok(W, H, g)) {
+            OFC_TRY(launch_polyexp_u8(frames_dev, R, n_frames, W, H, f->pc, s));
+        } else {
+            OFC_TRY(launch_level_image(frames_dev, I, n_frames, W, H, g, s));
+            OFC_TRY(launch_polyexp(I, R, n_frames, g.w, g.h, f->pc, 0, s));
+        }
         const size_t strideR = 5 * P;
         const float mul = (float)(1. / f->prm.pyr_scale);
         if (f->fused) {
@@ -316,6 +321,7 @@ int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_ba
     {
         const char *e = getenv("OFC_FLOW_STAGED");      // debugging aid: force the separate K4 / K5 kernels
         f->fused = prm.winsize <= 15 && !(e && e[0] == '1');
+        f->fuse_level0 = !(e && e[0] == '1');            // the staged mode also keeps the separate level-0 image
     }
     if (f->fused) {
         OFC_TRY(f->flowC.alloc(sizeof(float) * 2 * P0 * nb));
@@ -493,6 +499,26 @@ int ofc_polyexp(int device, const float *img, int W, int H, int n, double sigma,
     OFC_HIP(hipMemcpy(I.p, img, sizeof(float) * P, hipMemcpyHostToDevice));
     OFC_TRY(launch_polyexp(I.as<float>(), R.as<float>(), 1, W, H, pc, 0, nullptr));
     OFC_HIP(hipMemcpy(R5, R.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));   // already pixel-interleaved
+    return OFC_OK;
+}
+
+int ofc_polyexp_u8(int device, const uint8_t *gray, int W, int H, int n, double sigma, float *R5)
+{
+    OFC_REQUIRE(gray && R5 && W >= 1 && H >= 1, "bad arguments");
+    if (n != 5) { set_error("poly_n %d unsupported (5 only)", n); return OFC_EUNSUPPORTED; }
+    OFC_TRY(ensure_device(device));
+    ofc_fb_params prm = {0.5, 0, 15, 3, 5, sigma, 0};
+    const LevelGeom g = level_geometry(W, H, prm, 0);
+    if (!polyexp_u8_ok(W, H, g)) { set_error("fused level-0 expansion needs W >= 4 and H >= 2"); return OFC_EUNSUPPORTED; }
+    const size_t P = (size_t)W * H;
+    PolyConsts pc;
+    polyexp_setup(n, sigma, pc);
+    DevBuf I, R;
+    OFC_TRY(I.alloc(P));
+    OFC_TRY(R.alloc(sizeof(float) * 5 * P));
+    OFC_HIP(hipMemcpy(I.p, gray, P, hipMemcpyHostToDevice));
+    OFC_TRY(launch_polyexp_u8(I.as<uint8_t>(), R.as<float>(), 1, W, H, pc, nullptr));
+    OFC_HIP(hipMemcpy(R5, R.p, sizeof(float) * 5 * P, hipMemcpyDeviceToHost));
     return OFC_OK;
 }
 

@@ -86,6 +86,9 @@ void polyexp_setup(int n, double sigma, PolyConsts &c);        // FarnebackPrepa
 // src: [nimg][H0][W0] u8 -> dst: [nimg][h][w] f32
 int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
                        const LevelGeom &g, hipStream_t s);
+// level 0 fused into the polynomial expansion (frames u8 -> R), when the level is the plain 3x3 blur of the frame
+bool polyexp_u8_ok(int W, int H, const LevelGeom &g);
+int launch_polyexp_u8(const uint8_t *frames, float *R, int nimg, int W, int H, const PolyConsts &c, hipStream_t s);
 // I: [nimg][H][W] f32 -> R: [nimg][H][W][5] f32 (pixel-interleaved)
 int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyConsts &c,
                    int rows_per_block, hipStream_t s, bool bench_tag = false);

@@ -26,6 +26,15 @@ def polyexp(img, n=5, sigma=1.2, device=0):
     return out
 
 
+def polyexp_u8(gray, n=5, sigma=1.2, device=0):
+    """polyexp of pyramid level 0 straight from the u8 frame (the fused form the flow engine runs)"""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    out = np.empty((H, W, 5), np.float32)
+    check(load().ofc_polyexp_u8(device, ptr(gray), W, H, n, sigma, ptr(out)))
+    return out
+
+
 def update_matrices(R0, R1, flow, device=0):
     R0, R1, flow = (np.ascontiguousarray(a, np.float32) for a in (R0, R1, flow))
     H, W = flow.shape[:2]

@@ -191,3 +191,23 @@ def test_flow_on_unrelated_content_stays_within_relative_bar():
     assert rel(got, want) <= 1e-4
     assert np.abs(got - want).max() <= 0.1
     assert (np.abs(got - want).max(-1) > 1e-3).mean() < 0.02
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (67, 121), (40, 250), (33, 483), (17, 16), (16, 19), (21, 17)])
+def test_fused_level0_polyexp_is_bit_identical(shape):
+    """the flow engine's level 0 expands the u8 frame directly (3x3 blur evaluated on the fly, exact in f32):
+    must equal level image -> polyexp bit for bit, borders and odd sizes included"""
+    from opticalflowclustering_amd import stages
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    gray = rng.integers(0, 256, shape, dtype=np.uint8)
+    gray[: shape[0] // 2, : shape[1] // 3] = 255
+    want = stages.polyexp(stages.level_image(gray, 0))
+    got = stages.polyexp_u8(gray)
+    assert np.array_equal(got, want)
+
+
+def test_fused_level0_polyexp_rejects_tiny_frames():
+    from opticalflowclustering_amd import stages
+    from opticalflowclustering_amd._lib import OfcError
+    with pytest.raises(OfcError):
+        stages.polyexp_u8(np.zeros((8, 3), np.uint8))
