@@ -186,6 +186,13 @@ int ofc_lloyd_farthest_dev(int device, const void *X_dev, int dtype, int64_t N, 
                            const double *centers_c, const uint8_t *labels_dev, const int64_t *excl, int n_excl,
                            double *dist2, int64_t *index, double *x_c, int *label);
 
+/* one step of k-means++ seeding (sklearn's default init for KMeans(n_clusters=k), the reference's construction at
+ * color_kmeans.py:66, KmeanGrids.py:300; algorithm: sklearn/cluster/_kmeans.py:230-262): squared distances of all N
+ * samples (centred by `mean`) to the rows X[cand[c]], c < n_cand <= 8, in the expanded form sklearn evaluates,
+ * element-wise minimum with closest[] when it is not NULL; out_min [n_cand][N] f64, pots[c] = sum_i out_min[c][i].
+ * The random draws, the cumulative sum and searchsorted stay on the host (cluster.kmeans_plusplus). */
+int ofc_kpp_candidates(int device, const void *X, int dtype, int64_t N, int d, const double *mean,
+                       const int64_t *cand, int n_cand, const double *closest, double *out_min, double *pots);
 /* many small independent problems in one launch (the per-grid-cell shape of KmeanGrids.py:376-392):
  * problem p owns rows [offsets[p], offsets[p+1]) of X (u8, d = 4); init/centers: P x k x d f64;
  * counts: P x k i32 = np.bincount(predict(X)); labels may be NULL. */

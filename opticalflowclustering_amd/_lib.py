@@ -76,6 +76,7 @@ _PROTOS = {
     "ofc_lloyd_step_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
     "ofc_lloyd_inertia_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, C.POINTER(_d)], _i),
     "ofc_lloyd_farthest_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(_d), C.POINTER(_i64), _vp, _ip], _i),
+    "ofc_kpp_candidates": ([_i, _vp, _i, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "ofc_kmeans_fit_batched": ([_i, _vp, _vp, _i, _i, _i, _vp, _i, _d, _vp, _vp, _vp, _vp], _i),
     "ofc_grid_kmeans": ([_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _vp], _i),
     "ofc_grid_kmeans_dev": ([_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _vp], _i),

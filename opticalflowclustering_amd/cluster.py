@@ -5,10 +5,12 @@
 Semantics follow sklearn (cast to float64 math, centring, tol = 1e-4 * mean(var), strict-then-tol
 convergence, final E-step, empty-cluster relocation).  One deliberate difference: the reference
 constructs KMeans(n_clusters=k) with sklearn's default init='k-means++', random_state=None, i.e. a
-non-deterministic seeding.  Here `init` is either an explicit (k, d) array or
-'seeded-rows' (k distinct rows of X picked by numpy's default_rng(random_state), default seed 0),
-which keeps runs reproducible; for the reference's documented k=1 the result does not depend on
-the seeding at all."""
+non-deterministic seeding.  Here `init` is an explicit (k, d) array, 'seeded-rows'
+(the default: k distinct rows of X picked by numpy's default_rng(random_state), seed 0 -- reproducible), or
+'k-means++': sklearn's own seeding (_kmeans.py:174-272) with numpy-RandomState-compatible draws, so that
+KMeans(n_clusters=k, init='k-means++', random_state=s) lands on the centres sklearn finds for the same seed
+(random_state=None then means numpy's global RandomState, as in sklearn).  For the reference's documented k=1
+the result does not depend on the seeding at all."""
 import ctypes as C
 
 import numpy as np
@@ -38,6 +40,60 @@ def seeded_rows_init(X, k, random_state=0):
     return X[rng.choice(len(X), k, replace=len(X) < k)].astype(np.float64)
 
 
+def check_random_state(seed):
+    """sklearn.utils.check_random_state: None -> numpy's global RandomState, int -> RandomState(seed)"""
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, (int, np.integer)):
+        return np.random.RandomState(int(seed))
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError(f"{seed!r} cannot be used to seed a numpy.random.RandomState instance")
+
+
+def kmeans_plusplus(X, n_clusters, random_state=None, n_local_trials=None, device=0, _step=None):
+    """sklearn's _kmeans_plusplus (_kmeans.py:174-272) as KMeans.fit runs it: on the column-centred data, unit sample
+    weights.  The O(N d trials) part of every step -- distances of all samples to the candidate rows, the minimum
+    with the running closest distance, the candidates' potentials -- is one libofc launch (ofc_kpp_candidates); the
+    RandomState draws, np.cumsum and searchsorted are numpy's, in sklearn's order.  -> (centres (k,d) f64 rows of X,
+    indices).  The distances are not bit-identical to BLAS's (different summation order inside the dot product), so
+    agreement with sklearn is exact unless a random value falls within ~1e-16 (relative) of a cumulative-sum
+    boundary; tests/golden/kpp_goldens.npz pins it for a spread of seeds and shapes."""
+    X = _as_supported(X)
+    N, d = X.shape
+    rs = check_random_state(random_state)
+    if n_local_trials is None:
+        n_local_trials = 2 + int(np.log(n_clusters))                              # :217-221
+    if n_local_trials > 8:
+        raise ValueError("n_local_trials > 8 is not supported")
+    mean = X.astype(np.float64).mean(axis=0) if X.dtype != np.float32 else X.mean(axis=0).astype(np.float64)
+    weight = np.ones(N, np.float64)
+    indices = np.full(n_clusters, -1, dtype=np.int64)
+    indices[0] = rs.choice(N, p=weight / weight.sum())                            # :224
+
+    def step(cand, closest):
+        cand = np.ascontiguousarray(cand, np.int64)
+        if _step is not None:                    # tests: the CPU oracle stands in for the device step
+            return _step(X, mean, cand, closest)
+        out = np.empty((len(cand), N), np.float64)
+        pots = np.empty(len(cand), np.float64)
+        check(load().ofc_kpp_candidates(device, ptr(X), _DT[X.dtype], N, d, ptr(mean), ptr(cand), len(cand),
+                                        ptr(closest) if closest is not None else None, ptr(out), ptr(pots)))
+        return out, pots
+
+    out, pots = step(indices[:1], None)                                           # :233-236
+    closest, current_pot = out[0], pots[0]
+    for c in range(1, n_clusters):
+        rand_vals = rs.uniform(size=n_local_trials) * current_pot                  # :242
+        candidate_ids = np.searchsorted(np.cumsum(closest, dtype=np.float64), rand_vals)   # :243-245
+        np.clip(candidate_ids, None, N - 1, out=candidate_ids)                    # :247
+        out, pots = step(candidate_ids, closest)                                  # :250-256
+        best = int(np.argmin(pots))                                               # :259
+        current_pot, closest = pots[best], out[best]
+        indices[c] = candidate_ids[best]
+    return X[indices].astype(np.float64), indices
+
+
 class KMeans:
     def __init__(self, n_clusters=8, *, init="seeded-rows", n_init=1, max_iter=300, tol=1e-4,
                  random_state=0, device=0, **_ignored):
@@ -46,9 +102,11 @@ class KMeans:
 
     def _init_centers(self, X):
         if isinstance(self.init, str):
-            if self.init not in ("seeded-rows", "k-means++", "random"):
-                raise ValueError(f"init should be an array or 'seeded-rows', got {self.init!r}")
-            return seeded_rows_init(X, self.n_clusters, self.random_state)
+            if self.init == "k-means++":
+                return kmeans_plusplus(X, self.n_clusters, self.random_state, device=self.device)[0]
+            if self.init not in ("seeded-rows", "random"):
+                raise ValueError(f"init should be an array, 'k-means++' or 'seeded-rows', got {self.init!r}")
+            return seeded_rows_init(X, self.n_clusters, self.random_state if self.random_state is not None else 0)
         C0 = np.ascontiguousarray(self.init, np.float64)
         if C0.shape != (self.n_clusters, X.shape[1]):
             raise ValueError(f"The shape of the initial centers {C0.shape} does not match "

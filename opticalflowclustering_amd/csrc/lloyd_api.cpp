@@ -458,4 +458,44 @@ int ofc_kmeans_predict(int device, const void *X, int dtype, int64_t N, int d, i
     return OFC_OK;
 }
 
+/* see include/ofc.h */
+int ofc_kpp_candidates(int device, const void *X, int dtype, int64_t N, int d, const double *mean,
+                       const int64_t *cand, int n_cand, const double *closest, double *out_min, double *pots)
+{
+    OFC_REQUIRE(X && mean && cand && out_min && pots && N >= 1, "bad arguments");
+    OFC_REQUIRE(dtype >= OFC_U8 && dtype <= OFC_F64, "bad dtype %d", dtype);
+    OFC_REQUIRE(n_cand >= 1 && n_cand <= 8, "n_cand %d outside 1..8", n_cand);
+    OFC_TRY(check_kd(1, d));
+    for (int c = 0; c < n_cand; c++) OFC_REQUIRE(cand[c] >= 0 && cand[c] < N, "candidate index out of range");
+    OFC_TRY(ensure_device(device));
+    const size_t es = dtype_size(dtype);
+    std::vector<double> cc((size_t)n_cand * d);
+    for (int c = 0; c < n_cand; c++)
+        for (int f = 0; f < d; f++) {
+            const char *p = (const char *)X + ((size_t)cand[c] * d + f) * es;
+            const double v = dtype == OFC_U8 ? (double)*(const uint8_t *)p
+                           : dtype == OFC_F32 ? (double)*(const float *)p : *(const double *)p;
+            cc[(size_t)c * d + f] = v - mean[f];
+        }
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N, 256), 1024));
+    DevBuf Xd, cl, out, partial, tot;
+    OFC_TRY(Xd.alloc((size_t)N * d * es));
+    OFC_TRY(out.alloc(sizeof(double) * (size_t)N * n_cand));
+    OFC_TRY(partial.alloc(sizeof(double) * 8 * nblocks));
+    OFC_TRY(tot.alloc(sizeof(double) * 8));
+    OFC_HIP(hipMemcpy(Xd.p, X, (size_t)N * d * es, hipMemcpyHostToDevice));
+    if (closest) {
+        OFC_TRY(cl.alloc(sizeof(double) * N));
+        OFC_HIP(hipMemcpy(cl.p, closest, sizeof(double) * N, hipMemcpyHostToDevice));
+    }
+    OFC_TRY(launch_kpp_candidates(Xd.p, dtype, N, d, mean, cc.data(), n_cand, closest ? cl.as<double>() : nullptr,
+                                  out.as<double>(), partial.as<double>(), nblocks, nullptr));
+    OFC_TRY(launch_reduce_records(partial.as<double>(), nblocks, 8, tot.as<double>(), nullptr));
+    double t[8];
+    OFC_HIP(hipMemcpy(t, tot.p, sizeof(t), hipMemcpyDeviceToHost));
+    for (int c = 0; c < n_cand; c++) pots[c] = t[c];
+    OFC_HIP(hipMemcpy(out_min, out.p, sizeof(double) * (size_t)N * n_cand, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
 }  // extern "C"

@@ -55,6 +55,10 @@ int launch_lloyd_farthest(const void *X, int dtype, int64_t N, int d, const Lloy
                           const double *c_old, const uint8_t *labels, const int64_t *excl, int n_excl,
                           double *out, int nblocks, hipStream_t s);
 
+// k-means++ seeding step; partial: [nblocks][8] potentials per candidate
+int launch_kpp_candidates(const void *X, int dtype, int64_t N, int d, const double *mean, const double *cand_centred,
+                          int n_cand, const double *closest, double *out, double *partial, int nblocks, hipStream_t s);
+
 // distributed plumbing (dist.cpp): no-ops when no communicator is set up
 bool dist_active();
 int dist_rank();

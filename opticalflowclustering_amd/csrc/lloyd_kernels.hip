@@ -668,4 +668,88 @@ int launch_lloyd_farthest(const void *X, int dtype, int64_t N, int d, const Lloy
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-means++ seeding step (_kmeans_plusplus, sklearn/cluster/_kmeans.py:230-262): squared distances of every (centred)
+// sample to NC candidate rows in sklearn's expanded form max(0, (|c|^2 - 2 c.x) + |x|^2), minimum with the running
+// closest distance, per-work-group potential partials.  out: [NC][N] f64, partial: [block][KPP_MAXC].
+// ------------------------------------------------------------------------------------------------
+constexpr int KPP_MAXC = 8;
+struct KppArgs {
+    double mean[LLOYD_DMAX];
+    double cand[KPP_MAXC][LLOYD_DMAX];     // centred candidate rows
+    int n_cand;
+};
+
+template <int D, class T>
+__global__ __launch_bounds__(256) void k_kpp_candidates(const T *__restrict__ X, int64_t N, KppArgs a,
+                                                        const double *__restrict__ closest /* or null */,
+                                                        double *__restrict__ out, double *__restrict__ partial)
+{
+#pragma clang fp contract(off)
+    __shared__ double lds[4 * KPP_MAXC];
+    double cc[KPP_MAXC], pot[KPP_MAXC];
+#pragma unroll
+    for (int c = 0; c < KPP_MAXC; c++) {
+        double t = 0;
+#pragma unroll
+        for (int f = 0; f < D; f++) t += a.cand[c][f] * a.cand[c][f];
+        cc[c] = t;
+        pot[c] = 0;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        double x[D];
+        load1<D>(X, i, x);
+        double xx = 0;
+#pragma unroll
+        for (int f = 0; f < D; f++) {
+            x[f] -= a.mean[f];
+            xx += x[f] * x[f];
+        }
+        const double cl = closest ? closest[i] : 0.0;
+#pragma unroll
+        for (int c = 0; c < KPP_MAXC; c++) {
+            if (c < a.n_cand) {
+                double dot = 0;
+#pragma unroll
+                for (int f = 0; f < D; f++) dot += a.cand[c][f] * x[f];
+                double dd = (-2.0 * dot + cc[c]) + xx;
+                dd = dd > 0.0 ? dd : 0.0;
+                if (closest) dd = dd < cl ? dd : cl;
+                out[(size_t)c * N + i] = dd;
+                pot[c] += dd;
+            }
+        }
+    }
+    block_reduce_store<KPP_MAXC>(pot, lds, partial + (size_t)blockIdx.x * KPP_MAXC);
+}
+
+template <int D>
+static int launch_kpp_d(const void *X, int dtype, int64_t N, const KppArgs &a, const double *closest, double *out,
+                        double *partial, int nblocks, hipStream_t s)
+{
+    switch (dtype) {
+    case OFC_U8: hipLaunchKernelGGL((k_kpp_candidates<D, uint8_t>), dim3(nblocks), dim3(256), 0, s, (const uint8_t *)X, N, a, closest, out, partial); break;
+    case OFC_F32: hipLaunchKernelGGL((k_kpp_candidates<D, float>), dim3(nblocks), dim3(256), 0, s, (const float *)X, N, a, closest, out, partial); break;
+    case OFC_F64: hipLaunchKernelGGL((k_kpp_candidates<D, double>), dim3(nblocks), dim3(256), 0, s, (const double *)X, N, a, closest, out, partial); break;
+    default: set_error("bad dtype %d", dtype); return OFC_EINVAL;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+int launch_kpp_candidates(const void *X, int dtype, int64_t N, int d, const double *mean, const double *cand_centred,
+                          int n_cand, const double *closest, double *out, double *partial, int nblocks, hipStream_t s)
+{
+    if (n_cand < 1 || n_cand > KPP_MAXC) { set_error("n_cand %d outside 1..%d", n_cand, KPP_MAXC); return OFC_EUNSUPPORTED; }
+    KppArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_cand = n_cand;
+    for (int f = 0; f < d; f++) a.mean[f] = mean[f];
+    for (int c = 0; c < n_cand; c++)
+        for (int f = 0; f < d; f++) a.cand[c][f] = cand_centred[c * d + f];
+    int rc = OFC_OK;
+    OFC_D_SWITCH(d, { rc = launch_kpp_d<DD>(X, dtype, N, a, closest, out, partial, nblocks, s); })
+    return rc;
+}
+
 }  // namespace ofc

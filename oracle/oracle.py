@@ -272,3 +272,16 @@ def lloyd_partials(X, mean, centers_c, labels):
     lib().ofc_ref_lloyd_partials(_p(X), _DT[X.dtype], C.c_int64(N), d, k, _p(mean),
                                  _p(centers_c), _p(labels), _p(out))
     return out
+
+
+def kpp_candidates(X, mean, cand, closest=None):
+    """CPU restatement of one k-means++ seeding step (sklearn/cluster/_kmeans.py:250-256 with
+    _euclidean_distances' expanded form, metrics/pairwise.py): -> (min(closest, dist) [n_cand][N], potentials)"""
+    Xc = np.asarray(X, np.float64) - np.asarray(mean, np.float64)
+    Y = Xc[np.asarray(cand, np.int64)]
+    xx = (Xc * Xc).sum(axis=1)
+    yy = (Y * Y).sum(axis=1)
+    dist = np.maximum((-2.0 * (Y @ Xc.T) + yy[:, None]) + xx[None, :], 0.0)
+    if closest is not None:
+        dist = np.minimum(dist, np.asarray(closest, np.float64)[None, :])
+    return dist, dist.sum(axis=1)

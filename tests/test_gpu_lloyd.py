@@ -123,3 +123,33 @@ def test_dist_world1_allreduce():
     _lib.check(lib.ofc_dist_allreduce_f64(0, C.c_void_p(buf.ptr), 5))
     assert np.array_equal(buf.download((5,), np.float64), np.arange(5.0))
     _lib.check(lib.ofc_dist_finalize())
+
+
+KPP = np.load(os.path.join(os.path.dirname(__file__), "golden", "kpp_goldens.npz"))
+KPP_CASES = sorted({k.split("/")[0] for k in KPP.files})
+
+
+@pytest.mark.parametrize("name", KPP_CASES)
+def test_kmeans_plusplus_matches_sklearn_for_a_seed(KMeans, name):
+    """KMeans(n_clusters=k, init='k-means++', random_state=seed): same seed rows, labels, iteration count as sklearn"""
+    from opticalflowclustering_amd.cluster import kmeans_plusplus
+    from oracle import oracle as O
+    X, k, seed = KPP[name + "/X"], int(KPP[name + "/k"]), int(KPP[name + "/seed"])
+    _, idx = kmeans_plusplus(X, k, seed)
+    assert np.array_equal(idx, KPP[name + "/indices"])
+    # the device step against its CPU restatement
+    import ctypes as C
+    from opticalflowclustering_amd._lib import check, load, ptr
+    from opticalflowclustering_amd.cluster import _DT
+    mean = X.astype(np.float64).mean(axis=0)
+    cand = np.ascontiguousarray(idx[:3], np.int64)
+    closest = O.kpp_candidates(X, mean, idx[:1])[0][0]
+    out, pots = np.empty((3, len(X))), np.empty(3)
+    check(load().ofc_kpp_candidates(0, ptr(X), _DT[X.dtype], len(X), X.shape[1], ptr(mean), ptr(cand), 3, ptr(closest),
+                                    ptr(out), ptr(pots)))
+    want, wpots = O.kpp_candidates(X, mean, cand, closest)
+    assert np.allclose(out, want, rtol=1e-12, atol=1e-9) and np.allclose(pots, wpots, rtol=1e-12)
+    km = KMeans(n_clusters=k, init="k-means++", random_state=seed).fit(X)
+    assert km.n_iter_ == int(KPP[name + "/n_iter"])
+    assert np.array_equal(km.labels_, KPP[name + "/labels"])
+    assert np.allclose(km.cluster_centers_, KPP[name + "/centers"], rtol=1e-9, atol=1e-9)

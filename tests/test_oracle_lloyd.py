@@ -41,3 +41,18 @@ def test_partials_sum_to_full_step():
     a = O.lloyd_partials(X[:1000], mean, C0, np.full(1000, -1, np.int32))
     b = O.lloyd_partials(X[1000:], mean, C0, np.full(len(X) - 1000, -1, np.int32))
     assert np.array_equal(a + b, full)
+
+
+KPP = np.load(os.path.join(os.path.dirname(__file__), "golden", "kpp_goldens.npz"))
+KPP_CASES = sorted({k.split("/")[0] for k in KPP.files})
+
+
+@pytest.mark.parametrize("name", KPP_CASES)
+def test_kmeans_plusplus_host_logic_reproduces_sklearn_seeds(name):
+    """the numpy-RandomState draw order, cumsum/searchsorted and greedy candidate choice of cluster.kmeans_plusplus,
+    with the oracle standing in for the device step, pick the rows sklearn's _kmeans_plusplus picks"""
+    from opticalflowclustering_amd.cluster import kmeans_plusplus
+    X = KPP[name + "/X"]
+    centers, idx = kmeans_plusplus(X, int(KPP[name + "/k"]), int(KPP[name + "/seed"]), _step=O.kpp_candidates)
+    assert np.array_equal(idx, KPP[name + "/indices"])
+    assert np.array_equal(centers, X[idx].astype(np.float64))
