@@ -933,7 +933,12 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     constexpr int TXO = 256 - 2 * M;
     constexpr int NV = 2 * M + 4;
     constexpr int NV2 = (NV + 1) / 2;
-    constexpr int PITCH = 256 + 2;
+    // Vertical sums of one row cross LDS as PAIRS of doubles, even pairs in one plane and odd pairs in another: the
+    // horizontal pass's lane l reads pairs 2l .. 2l+8, so for a fixed q the 64 lanes read 64 consecutive 16-byte pairs
+    // of one plane (conflict-free ds_read_b128; with the plain [column] layout the 32-byte lane stride was a 4-way bank
+    // conflict: SQ_LDS_BANK_CONFLICT 1.3e8 of 2.2e8 LDS-active cycles per level-0 launch).  Plane pitch 136 doubles
+    // = 64 B mod 128: the writers' two interleaved 16-byte streams then cover every bank exactly twice.
+    constexpr int PLD = 136, PITCH = 2 * PLD;
     __shared__ __align__(16) double vs[5][BS_ROWS][PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware work-group -> (tile, pair) map.  Work-groups are dealt round-robin over the 8 XCDs, so ids L and
@@ -955,6 +960,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                                 : reinterpret_cast<const float2 *>(flow_inb) + (size_t)pair * plane;
     float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)pair * plane;
     const int xc = min(max(x0 - M + tid, 0), W - 1);
+    const int vs_w = ((tid >> 1) & 1) * PLD + 2 * (tid >> 2) + (tid & 1);     // this column's slot in a row of vs
     const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
     auto flow_at = [&](int row) -> float2 {
         if (UPS) return upsampled_flow(flow_in, ups.sw, ups.sh, ups.scx, ups.scy, ups.mul, xc, row);
@@ -1022,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     const int s_in = (4 * q4 + r + 1 + M) & 15, s_out = (4 * q4 + r + 16 - M) & 15;
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        vs[c][r][tid] = v[c];
+                        vs[c][r][vs_w] = v[c];
                         v[c] += (double)mi[r][c] - (double)ring[s_out][c];
                     }
 #pragma unroll
@@ -1038,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         double a[2 * NV2];
 #pragma unroll
                         for (int q = 0; q < NV2; q++) {
-                            double2 d = *reinterpret_cast<const double2 *>(&vs[c][wave][4 * lane + 2 * q]);
+                            double2 d = *reinterpret_cast<const double2 *>(&vs[c][wave][(q & 1) * PLD + 2 * (lane + (q >> 1))]);
                             a[2 * q] = d.x; a[2 * q + 1] = d.y;
                         }
                         double s = a[0];
