@@ -998,6 +998,14 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
         }
     }
 
+    // the flow vectors steer the gather addresses: fetched one step ahead (behind the current step's gathers) so that a
+    // step does not start with a second, dependent memory round trip.  (UPS computes them from 4 coarse taps: not
+    // worth 16 more loads in flight.)
+    float2 fln[BS_ROWS];
+    if (!UPS) {
+#pragma unroll
+        for (int r = 0; r < BS_ROWS; r++) fln[r] = flow_in[(size_t)min(y_begin + r + 1 + M, H - 1) * W + xc];
+    }
     for (int y16 = y_begin; y16 < y_end; y16 += 16) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
@@ -1008,12 +1016,17 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                 float mi[BS_ROWS][5];
 #pragma unroll
                 for (int r = 0; r < BS_ROWS; r++)
-                    fl[r] = flow_at(min(yc + r + 1 + M, H - 1));
+                    fl[r] = UPS ? flow_at(min(yc + r + 1 + M, H - 1)) : fln[r];
                 {
                     UmIn u[BS_ROWS];
 #pragma unroll
                     for (int q = 0; q < BS_ROWS; q++)            // the gathers of all four rows in flight together
                         um_load(R0, R1, plane, W, H, xc, min(yc + q + 1 + M, H - 1), fl[q], u[q]);
+                    if (!UPS) {
+#pragma unroll
+                        for (int r = 0; r < BS_ROWS; r++)
+                            fln[r] = flow_in[(size_t)min(yc + BS_ROWS + r + 1 + M, H - 1) * W + xc];
+                    }
 #pragma unroll
                     // rows below the image replicate row H-1: the loads above were clamped to it, and the same inputs give
                     // the same matrix entries again (no carried copy, no select)
