@@ -126,8 +126,9 @@ void ofc_ref_cart_to_polar(const float *x, const float *y, int64_t n, float *mag
 void ofc_ref_flow_to_bgr(const float *flow, int W, int H, uint8_t *bgr, float *mean_mag)
 {
     int64_t n = (int64_t)W * H;
+    if (n <= 0) return;
     float *mag = (float *)malloc(sizeof(float) * n), *ang = (float *)malloc(sizeof(float) * n);
-    float *u = (float *)malloc(sizeof(float) * n), *v = (float *)malloc(sizeof(float) * n);
+    float *u = (float *)calloc(n, sizeof(float)), *v = (float *)calloc(n, sizeof(float));
     uint8_t *hsv = (uint8_t *)malloc((size_t)n * 3);
     for (int64_t i = 0; i < n; i++) { u[i] = flow[i * 2]; v[i] = flow[i * 2 + 1]; }
     ofc_ref_cart_to_polar(u, v, n, mag, ang);
