@@ -966,6 +966,27 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
         if (UPS) return upsampled_flow(flow_in, ups.sw, ups.sh, ups.scx, ups.scy, ups.mul, xc, row);
         return flow_in[(size_t)row * W + xc];
     };
+    // UPS with the exact x2 pyramid: this thread's horizontal taps never change, and the 4 fine rows of a step touch only
+    // 3 or 4 distinct coarse rows -- interpolate each coarse row once per step (the arithmetic of upsampled_flow, shared)
+    const bool ups2 = UPS && ups.scx == 0.5 && ups.scy == 0.5;
+    int usx0 = 0, usx1 = 0;
+    float ua1 = 0.f;
+    if (ups2) {
+        const int sx = (xc + 1) / 2 - 1;
+        ua1 = (xc & 1) ? 0.25f : 0.75f;
+        usx0 = sx;
+        if (sx < 0) { ua1 = 0.f; usx0 = 0; }
+        if (sx >= ups.sw - 1) { ua1 = 0.f; usx0 = ups.sw - 1; }
+        usx1 = (ua1 == 0.f) ? usx0 : usx0 + 1;
+    }
+    auto coarse_row = [&](int sy) -> float2 {          // horizontally interpolated coarse flow at (clamped) row sy
+#pragma clang fp contract(off)
+        const float2 *rowp = flow_in + (size_t)min(max(sy, 0), ups.sh - 1) * ups.sw;
+        const float2 p0 = rowp[usx0], p1 = rowp[usx1];
+        if (ua1 == 0.f) return p0;
+        const float a0 = 1.f - ua1;
+        return make_float2(p0.x * a0 + p1.x * ua1, p0.y * a0 + p1.y * ua1);
+    };
 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
@@ -1014,9 +1035,27 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                 // ---- advance the window over the 4 rows of this step; loads batched two rows at a time ----
                 float2 fl[BS_ROWS];
                 float mi[BS_ROWS][5];
+                if (ups2 && yc + BS_ROWS + M <= H - 1) {            // uniform; no fine row of the step is clamped
+#pragma clang fp contract(off)
+                    const int e0 = yc + 1 + M, s0 = (e0 + 1) / 2 - 1;      // floor(0.5 e - 0.25) of the first fine row
+                    float2 hc[BS_ROWS];
 #pragma unroll
-                for (int r = 0; r < BS_ROWS; r++)
-                    fl[r] = UPS ? flow_at(min(yc + r + 1 + M, H - 1)) : fln[r];
+                    for (int j = 0; j < BS_ROWS; j++) hc[j] = coarse_row(s0 + j);
+#pragma unroll
+                    for (int r = 0; r < BS_ROWS; r++) {
+                        // yc = 0 (mod 4), so the parity of e0 is that of 1 + M: fine rows e0+r sit between coarse rows
+                        // s0 + off, s0 + off + 1 with off = 0,1,1,2 (e0 even) or 0,0,1,1 (e0 odd)
+                        constexpr bool E0_EVEN = ((1 + M) & 1) == 0;
+                        const int off = E0_EVEN ? (r + 1) / 2 : r / 2;
+                        const float b1 = (E0_EVEN == ((r & 1) == 0)) ? 0.75f : 0.25f, b0 = 1.f - b1;
+                        const float2 h0 = hc[off], h1 = hc[off + 1];
+                        fl[r] = make_float2((h0.x * b0 + h1.x * b1) * ups.mul, (h0.y * b0 + h1.y * b1) * ups.mul);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < BS_ROWS; r++)
+                        fl[r] = UPS ? flow_at(min(yc + r + 1 + M, H - 1)) : fln[r];
+                }
                 {
                     UmIn u[BS_ROWS];
 #pragma unroll

@@ -211,3 +211,23 @@ def test_fused_level0_polyexp_rejects_tiny_frames():
     from opticalflowclustering_amd._lib import OfcError
     with pytest.raises(OfcError):
         stages.polyexp_u8(np.zeros((8, 3), np.uint8))
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (726, 414), (250, 190)])
+def test_fused_engine_matches_staged_kernels(W, H, monkeypatch):
+    """the production path (level 0 fused into polyexp, upsample + update-matrices + box/solve fused into one iteration
+    kernel, coarse rows shared between the rows of a step) against the same engine running the separate stage kernels
+    (OFC_FLOW_STAGED=1): only the order of the exact f64 running sums differs"""
+    from opticalflowclustering_amd.flow import FlowEngine
+    p = synth.texture_params(4)
+    a = synth.frame(W, H, 0.0, 0.0, p).astype(np.uint8)
+    b = synth.frame(W, H, 2.3, -1.4, p).astype(np.uint8)
+    flows = []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("OFC_FLOW_STAGED", staged)
+        eng = FlowEngine(W, H)
+        flows.append(eng.calc(a, b))
+        eng.close()
+    d = np.abs(flows[0] - flows[1])
+    assert d.max() <= 2e-5, d.max()
+    assert (d == 0).mean() >= 0.9
