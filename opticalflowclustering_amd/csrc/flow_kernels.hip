@@ -1142,7 +1142,7 @@ int flow_iter_rows(int W, int H, int npair, int winsize)
     int64_t best_cost = LLONG_MAX;
     for (int n = 1; n <= 32; n++) {
         const int rows = cdiv(cdiv(H, n), 16) * 16;
-        if (rows < 32 && n > 1) break;
+        if (rows < 16 && n > 1) break;
         const int64_t blocks = (int64_t)tiles_x * cdiv(H, rows) * npair;
         const int64_t cost = cdiv64(blocks, resident) * (rows + winsize - 1);
         if (cost < best_cost) { best_cost = cost; best_rows = rows; }
