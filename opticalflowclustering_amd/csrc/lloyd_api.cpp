@@ -146,7 +146,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     LloydScratch &sc = scratch_for(device);
     OFC_TRY(sc.init());
     hipStream_t s = sc.stream;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
     if (!labels_dev) {
         if (sc.labels.bytes < (size_t)std::max<int64_t>(N, 1)) OFC_TRY(sc.labels.alloc((size_t)std::max<int64_t>(N, 1)));
         labels_dev = sc.labels.as<uint8_t>();
@@ -259,7 +259,7 @@ static int lloyd_predict_dev(int device, const void *X, int dtype, int64_t N, in
     OFC_HIP(hipMemset(st, 0, sizeof(LloydState)));
     OFC_HIP(hipMemcpy(st->centers, centers, sizeof(double) * k * d, hipMemcpyHostToDevice));
     OFC_TRY(launch_lloyd_set_centers(st, k, d, nullptr));
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
     OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, nullptr));
     OFC_HIP(hipStreamSynchronize(nullptr));
     return OFC_OK;
@@ -290,7 +290,7 @@ struct StepCtx {
     int nblocks = 1;
     int init(int64_t N, int nv)
     {
-        nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 2048));
+        nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
         OFC_TRY(state.alloc(sizeof(LloydState)));
         OFC_TRY(partial.alloc(sizeof(double) * (size_t)nblocks * std::max(nv, 2)));
         OFC_TRY(tot.alloc(sizeof(double) * (nv + 8)));

@@ -341,13 +341,22 @@ __device__ inline double np_sum_small_dev(const double *a, int n)
 // Follows _average_centers / _center_shift (_k_means_common.pyx:274-311) incl. the in-place quirk for
 // still-empty clusters.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, int k, int d, int kmax,
+__global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g, int k, int d, int kmax,
                                int after_reloc, int labelled, int first, double n_total, double tol_rel,
                                LloydStatus *status /* pinned host */)
 {
+    // one lane does the (tiny, strictly ordered) arithmetic; all 64 first stage its inputs in LDS so that it does not
+    // walk through ~150 dependent global loads (8.6 -> 4 us per iteration, which matters on a 1/8 shard)
+    constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1 + LLOYD_DMAX;
+    __shared__ double tot[NVMAX], cold[LLOYD_KMAX * LLOYD_DMAX], cnew[LLOYD_KMAX * LLOYD_DMAX];
+    __shared__ int s_halt;
+    const int NV = kmax * d + kmax + 1 + LLOYD_DMAX;
+    for (int i = threadIdx.x; i < NV; i += blockDim.x) tot[i] = tot_g[i];
+    for (int i = threadIdx.x; i < k * d; i += blockDim.x) cold[i] = st->centers[i];
+    if (threadIdx.x == 0) s_halt = st->halt;
+    __syncthreads();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->halt && !after_reloc) return;           // no-op behind a converged / stalled iteration
-    double *cnew = st->centers_new;
+    if (s_halt && !after_reloc) return;             // no-op behind a converged / stalled iteration
     const double *w = tot + kmax * d;
     int amax = 0, n_empty = 0;
     for (int j = 0; j < k; j++) {
@@ -381,7 +390,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
     // shift (4-way grouped squared distance, then sqrt, squared again and summed numpy-style)
     double sh2[LLOYD_KMAX];
     for (int j = 0; j < k; j++) {
-        const double *a = cnew + j * d, *b = st->centers + j * d;
+        const double *a = cnew + j * d, *b = cold + j * d;
         double r = 0;
         int f = 0;
         for (; f + 4 <= d; f += 4)
@@ -397,23 +406,28 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot, i
         double acc = cnew[j * d] * cnew[j * d];
         for (int f = 1; f < d; f++) acc = fma(cnew[j * d + f], cnew[j * d + f], acc);
         st->cn[j] = acc;
-        for (int f = 0; f < d; f++) st->centers[j * d + f] = cnew[j * d + f];
+        for (int f = 0; f < d; f++) {
+            st->centers[j * d + f] = cnew[j * d + f];
+            st->centers_new[j * d + f] = cnew[j * d + f];
+        }
     }
     // tol = mean(X.var(axis=0)) * tol_rel (_tolerance, _kmeans.py:279-287): the column sums of (x-mean)^2 ride along
     // with iteration 0's record
+    double tol = st->tol;
     if (first) {
         double var[LLOYD_DMAX];
         for (int f = 0; f < d; f++) var[f] = tot[kmax * d + kmax + 1 + f] / n_total;
-        st->tol = tol_rel != 0 ? np_sum_small_dev(var, d) / (double)d * tol_rel : 0.0;
+        tol = tol_rel != 0 ? np_sum_small_dev(var, d) / (double)d * tol_rel : 0.0;
+        st->tol = tol;
     }
     const double n_changed = tot[kmax * d + kmax];
     const int strict = labelled && n_changed == 0.0;
-    const int converged = strict || tot_shift <= st->tol;
+    const int converged = strict || tot_shift <= tol;
     st->halt = converged;
     status->n_changed = n_changed;
     for (int f = 0; f < d; f++) status->sqsum[f] = tot[kmax * d + kmax + 1 + f];
     status->shift_tot = tot_shift;
-    status->tol = st->tol;
+    status->tol = tol;
     status->n_empty = 0;
     status->converged = converged;
     status->strict = strict;
