@@ -87,6 +87,8 @@ CASES = [("t1", 480, 270, lambda W, H: synth.translated_pair(W, H, 1.5, -0.75)),
          ("nonrigid", 640, 360, lambda W, H: synth.nonrigid_pair(W, H)[:2]),
          ("noise", 256, 256, lambda W, H: synth.noise_pair(W, H)),
          ("odd", 322, 198, lambda W, H: synth.translated_pair(W, H, -2.2, 1.3)),
+         ("odd_both", 321, 199, lambda W, H: synth.translated_pair(W, H, 1.2, 2.1)),
+         ("tiny", 17, 16, lambda W, H: synth.translated_pair(W, H, 0.4, -0.3)),
          # low-texture / high-offset frames: where f32 accumulation in the polynomial expansion would show first
          ("flat_bright", 960, 540, lambda W, H: tuple(np.clip(248.0 + (f.astype(np.float64) - 127.5) * 0.04, 0, 255).astype(np.uint8)
                                                       for f in synth.translated_pair(W, H, 2.0, 1.0))),
