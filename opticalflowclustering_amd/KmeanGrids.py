@@ -20,7 +20,6 @@ import os
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, load, ptr
 from .computeOpticalFlowModule import ComputeOpticalFLow
 from .frameio import FrameSource, get_number  # noqa: F401  (get_number re-exported like the reference)

@@ -10,12 +10,10 @@ Conscious deviations:
     'cluster_centers.csv' in the CWD and raises if it is absent (D.2)."""
 import argparse
 import csv
-import ctypes as C
 import os
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, load, ptr
 from .cluster import KMeans
 from .frameio import imread_bgr

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FbParams, OfcError, check, load, ptr
+from ._lib import FbParams, check, load, ptr
 
 
 class FlowEngine:

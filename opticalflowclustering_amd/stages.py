@@ -4,7 +4,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
 from ._lib import FbParams, check, load, ptr
 
 

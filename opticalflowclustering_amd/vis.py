@@ -3,7 +3,6 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, load, ptr
 
 
