@@ -153,3 +153,34 @@ def test_kmeans_plusplus_matches_sklearn_for_a_seed(KMeans, name):
     assert km.n_iter_ == int(KPP[name + "/n_iter"])
     assert np.array_equal(km.labels_, KPP[name + "/labels"])
     assert np.allclose(km.cluster_centers_, KPP[name + "/centers"], rtol=1e-9, atol=1e-9)
+
+
+def test_fuzz_shapes_against_oracle(KMeans):
+    """seeded sweep over dtype x d x k x N (incl. N < 256, N not a multiple of 4, k up to 16, clustered and uniform
+    data): labels, iteration count and centres against the CPU oracle"""
+    rng = np.random.default_rng(2024)
+    n_checked = 0
+    for trial in range(36):
+        dtype = [np.uint8, np.float32, np.float64][trial % 3]
+        d = int(rng.integers(1, 5))
+        k = int(rng.choice([1, 2, 3, 5, 8, 9, 13, 16]))
+        N = int(rng.choice([k, k + 1, 37, 255, 257, 1023, 4099, 20001]))
+        N = max(N, k)
+        if trial % 2:
+            cen = rng.uniform(0, 200, (k, d))
+            X = cen[rng.integers(0, k, N)] + rng.normal(0, 6, (N, d))
+        else:
+            X = rng.uniform(0, 255, (N, d))
+        X = np.clip(X, 0, 255).astype(dtype)
+        rows = rng.choice(N, k, replace=False)
+        C0 = X[rows].astype(np.float64) + rng.normal(0, 0.5, (k, d))
+        cen, lab, inertia, n_it = O.kmeans_fit(X, C0)
+        km = KMeans(n_clusters=k, init=C0).fit(X)
+        msg = f"trial {trial}: dtype {np.dtype(dtype).name} d {d} k {k} N {N}"
+        assert km.n_iter_ == n_it, msg
+        assert np.array_equal(km.labels_, lab), msg
+        assert np.allclose(km.cluster_centers_, cen, rtol=1e-9, atol=1e-7), msg
+        assert abs(km.inertia_ - inertia) <= 1e-9 * max(1.0, abs(inertia)), msg
+        assert np.array_equal(km.predict(X), O.kmeans_predict(X, cen)), msg
+        n_checked += 1
+    assert n_checked == 36
