@@ -10,6 +10,8 @@
 // work-group -> fixed-order finishing kernel.  No atomics anywhere.
 #include "lloyd_common.h"
 
+#include <type_traits>
+
 namespace ofc {
 
 // ------------------------------------------------------------------------------------------------
@@ -195,11 +197,14 @@ __device__ __forceinline__ double sq_euclid_grouped(const double (&a)[D], const 
 // 3: M-step partials only -- labels are neither read nor written (2 of the 10 B/point of a float2 stream), record's
 // n_changed slot is 0: lloyd_fit_dev's loop does not need it while no cluster is empty (see there).
 template <int D, int KMAX, class T, int MODE>
-__global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k,
+__global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, int64_t N, int k_arg,
                                                       const LloydState *__restrict__ st,
                                                       uint8_t *__restrict__ labels,
                                                       double *__restrict__ partial, int first)
 {
+    // the launcher instantiates KMAX == k for k <= 8 (lloyd_kmax): a compile-time k removes the `j < k` masks from
+    // the distance loop (3 of 10 VALU instructions per cluster and sample)
+    const int k = KMAX <= 8 ? KMAX : k_arg;
     constexpr bool ACCUM = (MODE == 1 || MODE == 3), LABELS = (MODE != 3);
     if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
     constexpr int NV = KMAX * D + KMAX + 1 + LLOYD_DMAX;     // [sums][counts][changed][sum (x-mean)^2 per column]
@@ -232,10 +237,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     };
 
     const int64_t n4 = N / 4;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + tid; q < n4; q += (int64_t)gridDim.x * 256) {
-        double x[4][D];
-        load4<D>(X, q * 4, x);
-        const unsigned lo = MODE == 1 ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q) : 0u;
+    auto process = [&](int64_t q, double (&x)[4][D], unsigned lo) {
         const int old[4] = {(int)(lo & 255u), (int)((lo >> 8) & 255u), (int)((lo >> 16) & 255u), (int)(lo >> 24)};
         int nl[4];
 #pragma unroll
@@ -264,6 +266,37 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
         if (LABELS)
             __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)),
                                         reinterpret_cast<unsigned *>(labels) + q);
+    };
+    const int64_t q0 = (int64_t)blockIdx.x * 256 + tid, qs = (int64_t)gridDim.x * 256;
+    if constexpr (std::is_same<T, float>::value && D == 2) {
+        // the (u,v) stream: the next quad's 32 bytes are requested before the current quad is processed, which doubles
+        // the bytes each lane keeps in flight (1024 work-groups x 256 lanes x 32 B = 8 MB is less than what 5+ TB/s
+        // times the memory latency needs)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        auto raw = [&](int64_t q, v4f &a, v4f &b, unsigned &lo) {
+            a = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(X + q * 8));
+            b = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(X + q * 8 + 4));
+            lo = MODE == 1 ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q) : 0u;
+        };
+        v4f na = {0, 0, 0, 0}, nb = {0, 0, 0, 0};
+        unsigned nlo = 0;
+        if (q0 < n4) raw(q0, na, nb, nlo);
+        for (int64_t q = q0; q < n4; q += qs) {
+            const v4f a = na, b = nb;
+            const unsigned lo = nlo;
+            if (q + qs < n4) raw(q + qs, na, nb, nlo);
+            double x[4][D];
+            x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
+            x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
+            process(q, x, lo);
+        }
+    } else {
+        for (int64_t q = q0; q < n4; q += qs) {
+            double x[4][D];
+            load4<D>(X, q * 4, x);
+            const unsigned lo = MODE == 1 ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(labels) + q) : 0u;
+            process(q, x, lo);
+        }
     }
     if (blockIdx.x == 0 && tid < (int)(N - n4 * 4)) {
         const int64_t i = n4 * 4 + tid;
