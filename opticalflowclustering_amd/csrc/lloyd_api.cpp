@@ -8,6 +8,13 @@
 
 namespace ofc {
 
+// work-groups of a streaming sweep: enough lanes to keep the memory system full, few enough that the fixed-order record
+// reduction stays short (it is a visible share of an iteration on a 1/8 shard)
+static int lloyd_grid(int64_t N)
+{
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), N >= (200ll << 20) ? 2048 : 1024));
+}
+
 static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC_F32 ? 4 : 8); }
 
 // Per-device scratch, created once and reused by every fit: creating/destroying a HIP stream (1.5-6 ms) and
@@ -146,7 +153,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     LloydScratch &sc = scratch_for(device);
     OFC_TRY(sc.init());
     hipStream_t s = sc.stream;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
+    const int nblocks = lloyd_grid(N);
     if (!labels_dev) {
         if (sc.labels.bytes < (size_t)std::max<int64_t>(N, 1)) OFC_TRY(sc.labels.alloc((size_t)std::max<int64_t>(N, 1)));
         labels_dev = sc.labels.as<uint8_t>();
@@ -259,7 +266,7 @@ static int lloyd_predict_dev(int device, const void *X, int dtype, int64_t N, in
     OFC_HIP(hipMemset(st, 0, sizeof(LloydState)));
     OFC_HIP(hipMemcpy(st->centers, centers, sizeof(double) * k * d, hipMemcpyHostToDevice));
     OFC_TRY(launch_lloyd_set_centers(st, k, d, nullptr));
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
+    const int nblocks = lloyd_grid(N);
     OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, nullptr, nblocks, 0, 0, nullptr));
     OFC_HIP(hipStreamSynchronize(nullptr));
     return OFC_OK;
@@ -290,7 +297,7 @@ struct StepCtx {
     int nblocks = 1;
     int init(int64_t N, int nv)
     {
-        nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
+        nblocks = lloyd_grid(N);
         OFC_TRY(state.alloc(sizeof(LloydState)));
         OFC_TRY(partial.alloc(sizeof(double) * (size_t)nblocks * std::max(nv, 2)));
         OFC_TRY(tot.alloc(sizeof(double) * (nv + 8)));
