@@ -264,3 +264,29 @@ def test_draw_grids_stage_writes_cells_csv_and_video_and_feeds_color_kmeans_chan
             cen, _, _, _ = O.kmeans_fit(X, X[:1].astype(np.float64))
             want = int(O.bgr2hsv(np.rint(cen[0])[:3].astype(np.uint8).reshape(1, 1, 3))[0, 0, 0])
             assert got[frame_no][c] == want, (frame_no, c)
+
+
+def test_integration_md_binding_stub_runs(tmp_path):
+    """the ctypes stub INTEGRATION.md tells a maintainer of the reference to add (section B) is executed as written
+    (only the library path is made absolute) and must give what the package's own entry points give"""
+    import re
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.cluster import KMeans
+    from opticalflowclustering_amd.flow import FlowEngine
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# ofc_binding\.py.*?)```", md, re.S).group(1)
+    code = code.replace('C.CDLL("libofc.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "ofc_binding.py", "exec"), ns)
+    v = make_video(W=320, H=200, T=2)
+    a, b = O.bgr2gray(v[0]), O.bgr2gray(v[1])
+    got = ns["calcOpticalFlowFarneback"](a, b, None, 0.5, 3, 15, 3, 5, 1.2, 0)
+    eng = FlowEngine(320, 200)
+    assert np.array_equal(got, eng.calc(a, b))
+    eng.close()
+    X = v[0].reshape(-1, 3)[:5000]
+    C0 = X[[0, 17, 999]].astype(np.float64)
+    km = ns["KMeans"](3, init=C0).fit(X)
+    ref = KMeans(n_clusters=3, init=C0).fit(X)
+    assert np.array_equal(km.labels_, ref.labels_) and np.array_equal(km.cluster_centers_, ref.cluster_centers_)
+    assert km.n_iter_ == ref.n_iter_
