@@ -979,14 +979,22 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
         if (sx >= ups.sw - 1) { ua1 = 0.f; usx0 = ups.sw - 1; }
         usx1 = (ua1 == 0.f) ? usx0 : usx0 + 1;
     }
-    auto coarse_row = [&](int sy) -> float2 {          // horizontally interpolated coarse flow at (clamped) row sy
-#pragma clang fp contract(off)
+    auto coarse_taps = [&](int sy, float2 &p0, float2 &p1) {       // this thread's two taps of (clamped) coarse row sy
         const float2 *rowp = flow_in + (size_t)min(max(sy, 0), ups.sh - 1) * ups.sw;
-        const float2 p0 = rowp[usx0], p1 = rowp[usx1];
+        p0 = rowp[usx0];
+        p1 = rowp[usx1];
+    };
+    auto coarse_lerp = [&](float2 p0, float2 p1) -> float2 {        // horizontal interpolation of upsampled_flow
+#pragma clang fp contract(off)
         if (ua1 == 0.f) return p0;
         const float a0 = 1.f - ua1;
         return make_float2(p0.x * a0 + p1.x * ua1, p0.y * a0 + p1.y * ua1);
     };
+    // consecutive steps advance by two coarse rows: rows s0+2, s0+3 of a step are rows s0, s0+1 of the next (carried,
+    // interpolated), and the taps of the next step's two new rows are requested behind this step's gathers so that they
+    // travel during the horizontal pass, like the flow vectors of the non-UPS form
+    float2 hcar[2], pn[2][2];
+    bool have_next = false;
 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
@@ -1039,8 +1047,22 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma clang fp contract(off)
                     const int e0 = yc + 1 + M, s0 = (e0 + 1) / 2 - 1;      // floor(0.5 e - 0.25) of the first fine row
                     float2 hc[BS_ROWS];
+                    if (have_next) {                            // uniform
+                        hc[0] = hcar[0];
+                        hc[1] = hcar[1];
+                        hc[2] = coarse_lerp(pn[0][0], pn[0][1]);
+                        hc[3] = coarse_lerp(pn[1][0], pn[1][1]);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < BS_ROWS; j++) hc[j] = coarse_row(s0 + j);
+                        for (int j = 0; j < BS_ROWS; j++) {
+                            float2 p0, p1;
+                            coarse_taps(s0 + j, p0, p1);
+                            hc[j] = coarse_lerp(p0, p1);
+                        }
+                    }
+                    hcar[0] = hc[2];
+                    hcar[1] = hc[3];
+                    have_next = true;
 #pragma unroll
                     for (int r = 0; r < BS_ROWS; r++) {
                         // yc = 0 (mod 4), so the parity of e0 is that of 1 + M: fine rows e0+r sit between coarse rows
@@ -1055,9 +1077,14 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
                     for (int r = 0; r < BS_ROWS; r++)
                         fl[r] = UPS ? flow_at(min(yc + r + 1 + M, H - 1)) : fln[r];
+                    have_next = false;
                 }
                 {
                     UmIn u[BS_ROWS];
+                    // a wave that is ready to issue its gathers goes first: while its SIMD neighbour grinds through a
+                    // horizontal pass, all 36 requests of this step leave at once instead of trickling out between the
+                    // neighbour's VALU instructions (level-0 launch 783 -> 655 us)
+                    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int q = 0; q < BS_ROWS; q++)            // the gathers of all four rows in flight together
                         um_load(R0, R1, plane, W, H, xc, min(yc + q + 1 + M, H - 1), fl[q], u[q]);
@@ -1066,11 +1093,17 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         for (int r = 0; r < BS_ROWS; r++)
                             fln[r] = flow_in[(size_t)min(yc + BS_ROWS + r + 1 + M, H - 1) * W + xc];
                     }
+                    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                     // rows below the image replicate row H-1: the loads above were clamped to it, and the same inputs give
                     // the same matrix entries again (no carried copy, no select)
                     for (int r = 0; r < BS_ROWS; r++)
                         um_math(u[r], W, H, xc, min(yc + r + 1 + M, H - 1), fl[r], mi[r]);
+                }
+                if (UPS && have_next) {     // taps of coarse rows s0'+2, s0'+3 of the next step (the gathered operands are dead now)
+                    const int s0n = (yc + BS_ROWS + 1 + M + 1) / 2 - 1;
+                    coarse_taps(s0n + 2, pn[0][0], pn[0][1]);
+                    coarse_taps(s0n + 3, pn[1][0], pn[1][1]);
                 }
                 // the barrier that protects `vs` from the previous step's readers sits HERE, after this step's loads and
                 // matrix arithmetic: a wave that finished its horizontal pass early starts its gathers without waiting
