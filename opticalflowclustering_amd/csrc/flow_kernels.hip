@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         for (int r = 0; r < BS_ROWS; r++)
                             fln[r] = flow_in[(size_t)min(yc + BS_ROWS + r + 1 + M, H - 1) * W + xc];
                     }
-                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                     // rows below the image replicate row H-1: the loads above were clamped to it, and the same inputs give
                     // the same matrix entries again (no carried copy, no select)
@@ -1120,6 +1120,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     for (int c = 0; c < 5; c++) ring[s_in][c] = mi[r][c];
                 }
                 __syncthreads();
+                __builtin_amdgcn_s_setprio(0);
                 const int y = yc + wave;
                 const int xo = x0 + 4 * lane;
                 if (y < y_end && 4 * lane < TXO && xo < W) {
