@@ -999,28 +999,29 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
 
-    // ---- warm-up: rows y_begin-M .. y_begin+M (replicate-clamped), two at a time ----
+    // ---- warm-up: rows y_begin-M .. y_begin+M (replicate-clamped), four at a time (all flow vectors of a batch first,
+    //      then all gathers: two memory round trips per four rows; on the short strips of the coarse levels the warm-up
+    //      is a third of a work-group's life) ----
 #pragma unroll
-    for (int j2 = -M; j2 <= M; j2 += 2) {
-        float2 fl[2];
-        UmIn u[2];
+    for (int j4 = -M; j4 <= M; j4 += BS_ROWS) {
+        float2 fl[BS_ROWS];
+        UmIn u[BS_ROWS];
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int row = min(max(y_begin + j2 + q, 0), H - 1);
-            fl[q] = flow_at(row);
-        }
+        for (int q = 0; q < BS_ROWS; q++) fl[q] = flow_at(min(max(y_begin + j4 + q, 0), H - 1));
 #pragma unroll
-        for (int q = 0; q < 2; q++)
-            um_load(R0, R1, plane, W, H, xc, min(max(y_begin + j2 + q, 0), H - 1), fl[q], u[q]);
+        for (int q = 0; q < BS_ROWS; q++)
+            um_load(R0, R1, plane, W, H, xc, min(max(y_begin + j4 + q, 0), H - 1), fl[q], u[q]);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (j2 + q <= M) {
-                const int row = min(max(y_begin + j2 + q, 0), H - 1);
+        for (int q = 0; q < BS_ROWS; q++) {
+            if (j4 + q <= M) {
+                const int row = min(max(y_begin + j4 + q, 0), H - 1);
                 float m[5];
                 um_math(u[q], W, H, xc, row, fl[q], m);
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    ring[(j2 + q + 16) & 15][c] = m[c];
+                    ring[(j4 + q + 16) & 15][c] = m[c];
                     v[c] += (double)m[c];
                 }
             }
