@@ -923,7 +923,9 @@ __device__ __forceinline__ float2 upsampled_flow(const float2 *__restrict__ s, i
 // ------------------------------------------------------------------------------------------------
 // UPS: the first iteration of a level reads its initial flow straight from the coarser level (bilinear x2, times
 // 1/pyr_scale) instead of from a materialised upsampled copy -- K6 fused in, 16 B/px less traffic and one launch less.
-template <int M, bool UPS>
+// UPS = 0: flow_in is at this level's size; 1: bilinear upsample of the coarser level with general taps; 2: the exact x2
+// pyramid (pyr_scale 0.5 on even sizes), whose taps follow a fixed parity pattern (see below)
+template <int M, int UPS>
 __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
                                                       const float *__restrict__ flow_inb,
                                                       float *__restrict__ flow_outb, int W, int H,
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     };
     // UPS with the exact x2 pyramid: this thread's horizontal taps never change, and the 4 fine rows of a step touch only
     // 3 or 4 distinct coarse rows -- interpolate each coarse row once per step (the arithmetic of upsampled_flow, shared)
-    const bool ups2 = UPS && ups.scx == 0.5 && ups.scy == 0.5;
+    constexpr bool ups2 = UPS == 2;
     int usx0 = 0, usx1 = 0;
     float ua1 = 0.f;
     if (ups2) {
@@ -995,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     // travel during the horizontal pass, like the flow vectors of the non-UPS form
     float2 hcar[2], pn[2][2];
     bool have_next = false;
+    float2 fl_last = ups2 ? flow_at(H - 1) : make_float2(0.f, 0.f);   // flow of the last image row this thread has seen
 
     float ring[16][5];          // ring[row & 15] = M(clamp(row)); statically indexed everywhere below
     double v[5] = {0, 0, 0, 0, 0};
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                 // ---- advance the window over the 4 rows of this step; loads batched two rows at a time ----
                 float2 fl[BS_ROWS];
                 float mi[BS_ROWS][5];
-                if (ups2 && yc + BS_ROWS + M <= H - 1) {            // uniform; no fine row of the step is clamped
+                if (ups2) {
 #pragma clang fp contract(off)
                     const int e0 = yc + 1 + M, s0 = (e0 + 1) / 2 - 1;      // floor(0.5 e - 0.25) of the first fine row
                     float2 hc[BS_ROWS];
@@ -1073,12 +1076,13 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         const float b1 = (E0_EVEN == ((r & 1) == 0)) ? 0.75f : 0.25f, b0 = 1.f - b1;
                         const float2 h0 = hc[off], h1 = hc[off + 1];
                         fl[r] = make_float2((h0.x * b0 + h1.x * b1) * ups.mul, (h0.y * b0 + h1.y * b1) * ups.mul);
+                        // rows below the image replicate row H-1 (the gathers are clamped to it): so does their flow
+                        if (e0 + r > H - 1) fl[r] = fl_last; else fl_last = fl[r];      // uniform
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < BS_ROWS; r++)
                         fl[r] = UPS ? flow_at(min(yc + r + 1 + M, H - 1)) : fln[r];
-                    have_next = false;
                 }
                 {
                     UmIn u[BS_ROWS];
@@ -1101,7 +1105,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     for (int r = 0; r < BS_ROWS; r++)
                         um_math(u[r], W, H, xc, min(yc + r + 1 + M, H - 1), fl[r], mi[r]);
                 }
-                if (UPS && have_next) {     // taps of coarse rows s0'+2, s0'+3 of the next step (the gathered operands are dead now)
+                if (ups2) {                 // taps of coarse rows s0'+2, s0'+3 of the next step (the gathered operands are dead now)
                     const int s0n = (yc + BS_ROWS + 1 + M + 1) / 2 - 1;
                     coarse_taps(s0n + 2, pn[0][0], pn[0][1]);
                     coarse_taps(s0n + 3, pn[1][0], pn[1][1]);
@@ -1200,11 +1204,14 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
     case 2 * MM + 1: {                                                                                   \
         const int tx = cdiv(W, 256 - 2 * MM), ns = cdiv(H, rows_per_block);                              \
         dim3 grid(cdiv(tx * ns, 8) * 8 * npair);                                                         \
-        if (coarse)                                                                                      \
-            hipLaunchKernelGGL((k_flow_iter<MM, true>), grid, block, 0, s, R, frame_stride_R, flow_in,   \
+        if (coarse && u.scx == 0.5 && u.scy == 0.5)                                                      \
+            hipLaunchKernelGGL((k_flow_iter<MM, 2>), grid, block, 0, s, R, frame_stride_R, flow_in,      \
+                               flow_out, W, H, rows_per_block, u, tx, ns, npair);                        \
+        else if (coarse)                                                                                 \
+            hipLaunchKernelGGL((k_flow_iter<MM, 1>), grid, block, 0, s, R, frame_stride_R, flow_in,      \
                                flow_out, W, H, rows_per_block, u, tx, ns, npair);                        \
         else                                                                                             \
-            hipLaunchKernelGGL((k_flow_iter<MM, false>), grid, block, 0, s, R, frame_stride_R, flow_in,  \
+            hipLaunchKernelGGL((k_flow_iter<MM, 0>), grid, block, 0, s, R, frame_stride_R, flow_in,      \
                                flow_out, W, H, rows_per_block, u, tx, ns, npair);                        \
         break;                                                                                           \
     }

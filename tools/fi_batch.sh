@@ -8,9 +8,9 @@ python3 - "$b" <<'PY'
 import csv, glob, sys
 b = int(sys.argv[1])
 tr = list(csv.DictReader(open(glob.glob(f'gpurun_out/fib_{b}/**/*kernel_trace.csv', recursive=True)[0])))
-for pat in ('k_flow_iter<7, false>', 'k_flow_iter<7, true>', 'k_polyexp<0, true>'):
+for pat in ('k_flow_iter<7, 0>', 'k_flow_iter<7, 2>', 'k_polyexp<0, true>'):
     d = sorted(((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in tr if pat in r['Kernel_Name']), reverse=True)
-    frac = 2 / 9 if 'false' in pat and 'flow' in pat else (1 / 3 if 'flow' in pat else 1.0)
+    frac = 2 / 9 if '7, 0>' in pat else (1 / 3 if 'flow' in pat else 1.0)
     top = d[: max(1, int(len(d) * frac))]
     units = b if 'flow' in pat else b + 1
     print('batch %2d %-24s level-0 launches n=%d mean %.1f us -> %.2f us per %s' % (b, pat, len(top), sum(top) / len(top), sum(top) / len(top) / units, 'pair' if 'flow' in pat else 'frame'))

@@ -7,9 +7,9 @@ python3 - "$1" <<'PY'
 import csv, glob, sys
 tag = sys.argv[1]
 tr = list(csv.DictReader(open(glob.glob(f'gpurun_out/fi_{tag}/**/*kernel_trace.csv', recursive=True)[0])))
-d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in tr if 'k_flow_iter<7, false>' in r['Kernel_Name']]
+d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in tr if 'k_flow_iter<7, 0>' in r['Kernel_Name']]
 d.sort(reverse=True)
 n = len(d) // 4          # the level-0 launches are the slowest quarter... (2 of 9 per batch: top 2/9)
 top = d[: max(1, len(d) * 2 // 9)]
-print(tag, 'level-0 k_flow_iter<7,false>: n=%d mean %.1f us min %.1f us' % (len(top), sum(top) / len(top), min(top)))
+print(tag, 'level-0 k_flow_iter<7,0>: n=%d mean %.1f us min %.1f us' % (len(top), sum(top) / len(top), min(top)))
 PY
