@@ -184,3 +184,60 @@ def test_fuzz_shapes_against_oracle(KMeans):
         assert np.array_equal(km.predict(X), O.kmeans_predict(X, cen)), msg
         n_checked += 1
     assert n_checked == 36
+
+
+def _two_rank_worker(rank, conn, name, q):
+    """one of two processes sharing the GPU: its half of the rows on the device, the host-driven sharded driver, and a
+    pipe as the collective"""
+    import numpy as np
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.cluster import _DT
+    from opticalflowclustering_amd.pipeline import shard_pairs
+    from opticalflowclustering_amd.sharded import DeviceShard, fit_sharded
+    from tests.test_dist_gloo import make_case
+    X, C0 = make_case(name)
+    if X.dtype not in _DT:
+        X = X.astype(np.float64)
+    a, b = shard_pairs(len(X), 2, rank)
+    Xs = np.ascontiguousarray(X[a:b])
+    buf = _lib.DeviceBuffer(Xs.nbytes, 0)
+    buf.upload(Xs)
+    shard = DeviceShard(buf.ptr, _DT[Xs.dtype], len(Xs), Xs.shape[1])
+    fn = {"sum": np.add, "max": np.maximum, "min": np.minimum}
+
+    def allreduce(arr, op):
+        arr = np.ascontiguousarray(arr, np.float64)
+        conn.send(arr)
+        other = conn.recv()
+        return fn[op](arr, other) if rank == 0 else fn[op](other, arr)     # same operand order on both ranks
+
+    cen, inertia, n_iter = fit_sharded(shard, C0, allreduce=allreduce, rank=rank)
+    labels = np.empty(len(Xs), np.uint8)
+    _lib.check(_lib.load().ofc_memcpy_d2h(0, _lib.ptr(labels), shard.labels, len(Xs)))
+    q.put((rank, cen, inertia, n_iter, labels.astype(np.int32)))
+
+
+@pytest.mark.parametrize("name", ["uv", "reloc", "rgba"])
+def test_two_processes_share_the_gpu_sharded_driver(name):
+    """world size 2 on ONE GPU without RCCL: two processes, each with half of the rows resident on the device, run
+    sharded.fit_sharded over DeviceShard (the HIP kernels) with a pipe as the all-reduce -- must equal the single-process
+    oracle fit, including the relocation whose farthest sample lives on the other rank"""
+    import multiprocessing as mp
+    from tests.test_dist_gloo import make_case
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    c0, c1 = ctx.Pipe()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, c, name, q)) for r, c in ((0, c0), (1, c1))]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    X, C0 = make_case(name)
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, C0)
+    assert res[0][3] == res[1][3] == n_iter
+    assert np.array_equal(np.concatenate([res[0][4], res[1][4]]), lab)
+    for r in res:
+        assert np.abs(r[1] - cen).max() <= 1e-9 and abs(r[2] - inertia) <= 1e-10 * inertia
+    assert np.array_equal(res[0][1], res[1][1])
