@@ -84,6 +84,14 @@ def main():
     barrier()
     dt = allreduce_max(time.perf_counter() - t0)
     centers, inertia, n_iter = res
+    # extra, outside the timed region: the flow alone over the same resident clip (the configs[1] shape: many distinct
+    # 1080p pairs per launch sequence) -- reported as config.flow_only_mpx_s, not part of `value`
+    barrier()
+    tf = time.perf_counter()
+    for _ in range(2):
+        pipe.run_flow(sync=True)
+    barrier()
+    dt_flow = allreduce_max(time.perf_counter() - tf) / 2
 
     out = None
     if rank == 0:
@@ -106,6 +114,7 @@ def main():
                                    % (2 if world == 1 else 3, args.frames, world),
                        "width": W, "height": H, "frames": args.frames, "pairs": n_pairs_total, "k": K_CLUSTERS,
                        "lloyd_iters": int(n_iter), "flow_batch_pairs": pipe.batch,
+                       "flow_only_mpx_s": n_pairs_total * W * H / 1e6 / dt_flow,
                        "parallelism": "frames sharded x%d, RCCL all-reduce of k*(d+1)+1 f64 per Lloyd iteration" % world},
         }
         # ---- roofline leg: the polyexp kernel, HIP events on its own stream, 64 distinct 1080p images ----
