@@ -67,11 +67,20 @@ bool dist_active() { return g_comm != nullptr && g_world > 1; }
 int dist_rank() { return g_rank; }
 int dist_world() { return g_world; }
 
+bool dist_has_comm() { return g_comm != nullptr; }
+
 int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s)
+{
+    return dist_allreduce_f64(buf_dev, buf_dev, count, op, s);
+}
+
+// send != recv keeps the local contribution intact, so that issuing the same collective again (an iteration that was
+// enqueued speculatively and found the halt flag set) reproduces the same totals instead of summing totals
+int dist_allreduce_f64(const double *send_dev, double *recv_dev, int count, int op, hipStream_t s)
 {
     if (!g_comm) return OFC_OK;      // a world-1 communicator (OFC_FORCE_DIST rehearsal) still issues the collective
     const int nop = op == DIST_SUM ? NCCL_SUM : (op == DIST_MAX ? NCCL_MAX : NCCL_MIN);
-    OFC_NCCL(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, NCCL_FLOAT64, nop, g_comm, s));
+    OFC_NCCL(g_rccl.AllReduce(send_dev, recv_dev, (size_t)count, NCCL_FLOAT64, nop, g_comm, s));
     return OFC_OK;
 }
 

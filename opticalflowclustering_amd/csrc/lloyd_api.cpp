@@ -20,7 +20,7 @@ static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC
 // Per-device scratch, created once and reused by every fit: creating/destroying a HIP stream (1.5-6 ms) and
 // pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
-    DevBuf state, partial, tot, excl, far, labels;
+    DevBuf state, partial, tot, tot_local, excl, far, labels;
     LloydStatus *status = nullptr;       // pinned, device-visible; one slot per iteration of a window
     LloydStatus *status_dev = nullptr;
     hipStream_t stream = nullptr;
@@ -33,6 +33,7 @@ struct LloydScratch {
         OFC_TRY(state.alloc(sizeof(LloydState)));
         OFC_TRY(partial.alloc(sizeof(double) * 2048 * NVMAX));
         OFC_TRY(tot.alloc(sizeof(double) * (NVMAX + 8)));
+        OFC_TRY(tot_local.alloc(sizeof(double) * (NVMAX + 8)));
         OFC_TRY(excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
         OFC_TRY(far.alloc(sizeof(double) * 2 * 2048));
         OFC_HIP(hipHostMalloc((void **)&status, sizeof(LloydStatus) * LLOYD_WINDOW, hipHostMallocMapped));
@@ -201,14 +202,18 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     bool strict = false, labelled = false, stop = false;
     int it = 0;
     const int *halt = &st->halt;
+    double *tot_local = dist_has_comm() ? sc.tot_local.as<double>() : tot;
     while (it < max_iter && !stop) {
         const int nwin = std::min(LLOYD_WINDOW, max_iter - it);
         for (int w = 0; w < nwin; w++) sc.status[w].valid = 0;
         for (int w = 0; w < nwin; w++) {
             OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
                                         labelled ? 1 : 3, it + w == 0, s));
-            OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot, s, halt));
-            OFC_TRY(dist_allreduce_f64(tot, NV, DIST_SUM, s));
+            // with a communicator the local record goes to its own buffer and the collective writes `tot`: an iteration
+            // behind the halt flag then re-reduces the same local records into the same totals (in place it would sum
+            // the totals of all ranks again, and a stalled iteration's `tot` is what relocate_empty reads)
+            OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot_local, s, halt));
+            OFC_TRY(dist_allreduce_f64(tot_local, tot, NV, DIST_SUM, s));
             OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, labelled, it + w == 0, Ng, tol_rel, sc.status_dev + w, s));
         }
         OFC_HIP(hipStreamSynchronize(s));

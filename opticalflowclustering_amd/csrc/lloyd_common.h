@@ -64,6 +64,8 @@ bool dist_active();
 int dist_rank();
 int dist_world();
 enum { DIST_SUM = 0, DIST_MAX = 1, DIST_MIN = 2 };
-int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s);
+int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s);                      // in place
+int dist_allreduce_f64(const double *send_dev, double *recv_dev, int count, int op, hipStream_t s);
+bool dist_has_comm();
 
 }  // namespace ofc
