@@ -222,6 +222,10 @@ int ofc_grid_kmeans_dev(int device, const uint8_t *bgr_dev, int W, int H, int n_
 int ofc_dist_unique_id(uint8_t id[OFC_UNIQUE_ID_BYTES]);          /* rank 0, then broadcast */
 int ofc_dist_init(int device, int rank, int world, const uint8_t id[OFC_UNIQUE_ID_BYTES]);
 int ofc_dist_allreduce_f64(int device, double *buf_dev, int count); /* test hook */
+/* TEST HOOK: emulate `world` ranks that all hold the caller's shard, without a communicator (sums become world-fold,
+ * max/min unchanged, rank 0): lets one GPU exercise the N>1 control flow of ofc_kmeans_fit_dev -- the result must equal
+ * a single-rank fit over `world` concatenated copies of the shard.  world = 1 switches it off. */
+int ofc_dist_loopback(int world);
 int ofc_dist_finalize(void);
 
 /* ------------------------------------------------------------------------------------------

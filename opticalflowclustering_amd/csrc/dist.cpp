@@ -27,6 +27,7 @@ struct Rccl {
 static Rccl g_rccl;
 static ncclCommT g_comm = nullptr;
 static int g_rank = 0, g_world = 1, g_device = -1;
+static int g_loopback = 0;      // test hook: world size emulated without a communicator (see ofc_dist_loopback)
 
 static int load_rccl()
 {
@@ -63,11 +64,11 @@ static int load_rccl()
         }                                                                                       \
     } while (0)
 
-bool dist_active() { return g_comm != nullptr && g_world > 1; }
+bool dist_active() { return (g_comm != nullptr || g_loopback > 1) && g_world > 1; }
 int dist_rank() { return g_rank; }
 int dist_world() { return g_world; }
 
-bool dist_has_comm() { return g_comm != nullptr; }
+bool dist_has_comm() { return g_comm != nullptr || g_loopback > 1; }
 
 int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s)
 {
@@ -78,8 +79,9 @@ int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s)
 // enqueued speculatively and found the halt flag set) reproduces the same totals instead of summing totals
 int dist_allreduce_f64(const double *send_dev, double *recv_dev, int count, int op, hipStream_t s)
 {
+    if (g_loopback > 1) return launch_loopback_reduce(send_dev, recv_dev, count, g_loopback, op == DIST_SUM, s);
     if (!g_comm) return OFC_OK;      // a world-1 communicator (OFC_FORCE_DIST rehearsal) still issues the collective
-    const int nop = op == DIST_SUM ? NCCL_SUM : (op == DIST_MAX ? NCCL_MAX : NCCL_MIN);
+    const int nop = op == DIST_MAX ? NCCL_MAX : (op == DIST_MIN ? NCCL_MIN : NCCL_SUM);
     OFC_NCCL(g_rccl.AllReduce(send_dev, recv_dev, (size_t)count, NCCL_FLOAT64, nop, g_comm, s));
     return OFC_OK;
 }
@@ -123,8 +125,19 @@ int ofc_dist_allreduce_f64(int device, double *buf_dev, int count)
     return OFC_OK;
 }
 
+int ofc_dist_loopback(int world)
+{
+    OFC_REQUIRE(world >= 1 && world <= 64, "bad world");
+    OFC_REQUIRE(!g_comm, "a communicator is active");
+    g_loopback = world > 1 ? world : 0;
+    g_world = world > 1 ? world : 1;
+    g_rank = 0;
+    return OFC_OK;
+}
+
 int ofc_dist_finalize(void)
 {
+    g_loopback = 0;
     if (g_comm) {
         (void)hipSetDevice(g_device);
         (void)g_rccl.CommDestroy(g_comm);

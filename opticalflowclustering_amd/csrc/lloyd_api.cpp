@@ -120,7 +120,7 @@ static int relocate_empty(LloydScratch &sc, const void *X, int dtype, int64_t N,
         if (dist_active()) {
             double *dv = sc.far.as<double>();
             OFC_HIP(hipMemcpyAsync(dv, rec, sizeof(double) * (d + 1), hipMemcpyHostToDevice, s));
-            OFC_TRY(dist_allreduce_f64(dv, d + 1, DIST_SUM, s));
+            OFC_TRY(dist_allreduce_f64(dv, d + 1, DIST_BCAST, s));
             OFC_HIP(hipMemcpyAsync(rec, dv, sizeof(double) * (d + 1), hipMemcpyDeviceToHost, s));
             OFC_HIP(hipStreamSynchronize(s));
         }

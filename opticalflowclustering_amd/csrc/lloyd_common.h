@@ -63,9 +63,10 @@ int launch_kpp_candidates(const void *X, int dtype, int64_t N, int d, const doub
 bool dist_active();
 int dist_rank();
 int dist_world();
-enum { DIST_SUM = 0, DIST_MAX = 1, DIST_MIN = 2 };
+enum { DIST_SUM = 0, DIST_MAX = 1, DIST_MIN = 2, DIST_BCAST = 3 /* a sum to which exactly one rank contributes */ };
 int dist_allreduce_f64(double *buf_dev, int count, int op, hipStream_t s);                      // in place
 int dist_allreduce_f64(const double *send_dev, double *recv_dev, int count, int op, hipStream_t s);
 bool dist_has_comm();
+int launch_loopback_reduce(const double *send, double *recv, int count, int world, int sum, hipStream_t s);
 
 }  // namespace ofc

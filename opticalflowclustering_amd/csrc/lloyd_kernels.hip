@@ -799,4 +799,24 @@ int launch_kpp_candidates(const void *X, int dtype, int64_t N, int d, const doub
     return rc;
 }
 
+// test hook (ofc_dist_loopback): the all-reduce of W ranks that all hold the same shard -- a sum becomes W-fold repeated
+// addition of the local value, max / min / owner-broadcast leave it unchanged
+__global__ void k_loopback_reduce(const double *__restrict__ send, double *__restrict__ recv, int count, int world, int sum)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double v = send[i];
+    double r = v;
+    if (sum)
+        for (int w = 1; w < world; w++) r += v;
+    recv[i] = r;
+}
+
+int launch_loopback_reduce(const double *send, double *recv, int count, int world, int sum, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_loopback_reduce, dim3(cdiv(count, 64)), dim3(64), 0, s, send, recv, count, world, sum);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
 }  // namespace ofc

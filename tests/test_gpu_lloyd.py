@@ -241,3 +241,24 @@ def test_two_processes_share_the_gpu_sharded_driver(name):
     for r in res:
         assert np.abs(r[1] - cen).max() <= 1e-9 and abs(r[2] - inertia) <= 1e-10 * inertia
     assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("name,world", [("uv", 2), ("reloc", 2), ("uv", 8), ("rgba", 3)])
+def test_loopback_world_equals_fit_over_concatenated_copies(KMeans, name, world):
+    """the N>1 control flow of the in-library driver (all-reduced column sums / N, per-iteration totals in their own
+    buffer, speculative iterations behind the halt flag, the relocation exchange, all-reduced inertia) on one GPU:
+    ofc_dist_loopback(W) emulates W ranks that all hold this shard, so the fit must equal a single-rank fit over W
+    concatenated copies -- same labels, same iteration count, same centres, W-fold inertia"""
+    from opticalflowclustering_amd._lib import check, load
+    from tests.test_dist_gloo import make_case
+    X, C0 = make_case(name)
+    ref = KMeans(n_clusters=len(C0), init=C0).fit(np.concatenate([X] * world))
+    check(load().ofc_dist_loopback(world))
+    try:
+        km = KMeans(n_clusters=len(C0), init=C0).fit(X)
+    finally:
+        check(load().ofc_dist_loopback(1))
+    assert km.n_iter_ == ref.n_iter_
+    assert np.array_equal(km.labels_, ref.labels_[: len(X)])
+    assert np.allclose(km.cluster_centers_, ref.cluster_centers_, rtol=1e-11, atol=1e-11)
+    assert abs(km.inertia_ - ref.inertia_) <= 1e-10 * ref.inertia_
