@@ -290,3 +290,23 @@ def test_integration_md_binding_stub_runs(tmp_path):
     ref = KMeans(n_clusters=3, init=C0).fit(X)
     assert np.array_equal(km.labels_, ref.labels_) and np.array_equal(km.cluster_centers_, ref.cluster_centers_)
     assert km.n_iter_ == ref.n_iter_
+
+
+def test_color_kmeans_script_equals_per_file_runs(tmp_path):
+    """color_kmeans_script (the reference's per-file shell loop, batched into one launch) must append the rows that
+    running color_kmeans.py -c 1 file by file appends"""
+    from opticalflowclustering_amd import color_kmeans, color_kmeans_script
+    from opticalflowclustering_amd.frameio import imwrite_bgr
+    rng = np.random.default_rng(12)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(7):
+        img = rng.integers(0, 256, (40 + i, 50, 3), dtype=np.uint8)
+        img[rng.random(img.shape[:2]) < 0.6] = 0
+        imwrite_bgr(str(d / f"{i:04d}.png"), img)
+    a, b = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    assert color_kmeans_script.main([str(d), a]) == 0
+    for n in sorted(os.listdir(d)):
+        color_kmeans.main(["-i", str(d / n), "-c", "1", "-f", b])
+    assert open(a).read() == open(b).read()
+    assert len(open(a).read().splitlines()) == 8
