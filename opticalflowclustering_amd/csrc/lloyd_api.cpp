@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 namespace ofc {
 
@@ -25,6 +26,7 @@ struct LloydScratch {
     LloydStatus *status_dev = nullptr;
     hipStream_t stream = nullptr;
     bool ready = false;
+    std::mutex mu;                       // fits on one device share this scratch: serialised
     int init()
     {
         if (ready) return OFC_OK;
@@ -152,6 +154,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     const int kmax = lloyd_kmax(k);
     const int NV = lloyd_record_len(kmax, d);
     LloydScratch &sc = scratch_for(device);
+    std::lock_guard<std::mutex> lock(sc.mu);
     OFC_TRY(sc.init());
     hipStream_t s = sc.stream;
     const int nblocks = lloyd_grid(N);
