@@ -62,6 +62,8 @@ _PROTOS = {
     "ofc_update_matrices": ([_i, _vp, _vp, _vp, _i, _i, _vp], _i),
     "ofc_box_solve": ([_i, _vp, _i, _i, _i, _vp], _i),
     "ofc_flow_resize": ([_i, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "ofc_flow_iterate": ([_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "ofc_bench_flow_iters": ([_i, _i, _i, _i, _i, _i, C.POINTER(_f)], _i),
     "ofc_bench_polyexp": ([_i, _i, _i, _i, _i, _i, C.POINTER(_f)], _i),
     "ofc_bgr2gray": ([_i, _vp, _i, _i, _vp], _i),
     "ofc_flow_to_bgr": ([_i, _vp, _i, _i, _vp, C.POINTER(_f)], _i),

@@ -1232,6 +1232,236 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
 }
 
 // ------------------------------------------------------------------------------------------------
+// K4+K5 x2: TWO consecutive Farneback iterations  flow_in -> (flow_mid) -> flow_out  in one launch, so that the second
+// iteration finds R0/R1 in the L2 instead of in HBM (the three iterations of a level each used to stream both frames' R:
+// 2/3 of k_flow_iter's traffic).  flow_mid never exists in memory.
+//
+// Work-group = 2*C threads: waves [0, C/64) are stage A (first iteration), waves [C/64, C/32) stage B (second), thread <->
+// column of a C-column tile (C - 4m final outputs + 2m halo columns per side) exactly as in k_flow_iter: 16-row ring of M in
+// registers, f64 vertical running sums, LDS exchange for the horizontal sums, regularised 2x2 solve.  The march advances
+// TWO rows per step; stage A emits its flow rows into a 16-row ring in LDS ("link"), stage B runs LAG = 10 steps behind
+// (its warm-up needs A's first 16 rows), reads its flow vectors from the link and writes the final rows.  In steady state
+// B ingests the rows A ingested 12 rows earlier: a 256-column tile keeps ~(12 + 4 + |flow|) rows x 2 frames x 5 KB = 90 KB
+// of R per work-group alive, 32 work-groups (32 consecutive pairs of one tile, sharing frames) per XCD = 3 MB of its 4 MB L2.
+//
+// Every wave runs the same phases in lockstep (one work-group per CU: 120 KB LDS, 2 waves per SIMD), so memory latency is
+// hidden by software pipelining instead of by a second work-group: the gathers of step j+1 are issued right after the
+// step's barrier and land during the horizontal pass; the vertical sums cross LDS double-buffered (one barrier per step).
+//
+// Arithmetic per iteration is that of k_flow_iter (um_load / um_math, exact f64 sums, same solve); the horizontal sums are
+// formed for 2 outputs per lane instead of 4, so an f64 sum may round differently in its last bit (~1e-16 relative; a
+// flow value changes by one f32 ulp about once per few million pixels).
+// ------------------------------------------------------------------------------------------------
+constexpr int FI2_LAG = 10;
+
+// the flow fields are streamed (each vector read once and written once per launch): non-temporal, so that they do not push
+// the R rows stage B is about to re-read out of the L2
+__device__ __forceinline__ float2 ld_flow(const float2 *p)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st_flow(float2 *p, float2 v)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store((v2f){v.x, v.y}, reinterpret_cast<v2f *>(p));
+}
+
+template <int M, int C>
+__global__ __launch_bounds__(2 * C, 2) void k_flow_iter2(const float *__restrict__ Rb, size_t frame_stride_R,
+                                                         const float *__restrict__ flow_inb,
+                                                         float *__restrict__ flow_outb, int W, int H,
+                                                         int rows_per_block /* even */, int tiles_x, int n_strips,
+                                                         int npair)
+{
+    constexpr int NW = C / 64;                // waves per stage
+    constexpr int TXO = C - 4 * M;            // final outputs per tile row
+    constexpr int VP = C + 16;                // columns of a vertical-sum row (+ pad: a lane reads 16 consecutive)
+    __shared__ __align__(16) double vs[2][2][5][2][VP];        // [stage][step parity][channel][row of the step][column]
+    __shared__ __align__(16) float2 link[16][C];               // stage A's flow rows, slot = row & 15
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int stage = __builtin_amdgcn_readfirstlane(tid / C);          // wave-uniform
+    const int wl = __builtin_amdgcn_readfirstlane((tid / 64) % NW);     // wave within its stage
+    const int c = tid % C;
+    // XCD-aware work-group -> (tile, pair) map, as in k_flow_iter
+    const int tiles = tiles_x * n_strips;
+    const int group = blockIdx.x / (8 * npair), rem = blockIdx.x - group * (8 * npair);
+    const int pair = rem >> 3, tile = group * 8 + (rem & 7);
+    if (tile >= tiles) return;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * TXO;
+    const int y_begin = tile_y * rows_per_block;
+    const int y_end = min(y_begin + rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *R0 = Rb + (size_t)pair * frame_stride_R;
+    const float *R1 = R0 + frame_stride_R;
+    const float2 *flow_in = reinterpret_cast<const float2 *>(flow_inb) + (size_t)pair * plane;
+    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)pair * plane;
+    const int xc = min(max(x0 - 2 * M + c, 0), W - 1);                   // this thread's (clamped) image column
+    const int cl = min(max(xc - (x0 - 2 * M), M), C - M - 1);            // where stage A's flow of that column sits in a link row
+    const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+
+    // stage geometry: local step j ingests image rows yb - 8 + 2j + {0,1} (clamped) and, from j = 8 on, emits rows
+    // yb + 2(j-8) + {0,1}.  A starts 8 rows above B (B's first ingested row is A's first emitted one); at the top of the
+    // image both start at row 0 (rows above replicate row 0).
+    const int yb = stage ? y_begin : max(y_begin - 8, 0);
+    const int nB = 8 + (y_end - y_begin + 1) / 2;
+    const int nA = 8 + (min(y_begin + 2 * (nB - 8) + 7, H - 1) - yb) / 2 + 1;
+    const int nst = stage ? nB : nA;
+    const int lag = stage ? FI2_LAG : 0;
+    const int G = FI2_LAG + nB;
+
+    float ring[16][5];
+    double v[5] = {0, 0, 0, 0, 0};
+    UmIn u[2];
+    float2 fl[2], fln[2];
+    auto row_of = [&](int j, int r) -> int { return min(max(yb - 8 + 2 * j + r, 0), H - 1); };
+    // prologue: stage A requests the operands of its step 0 (and the flow vectors of step 1)
+    if (stage == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) fl[r] = ld_flow(flow_in + (size_t)row_of(0, r) * W + xc);
+#pragma unroll
+        for (int r = 0; r < 2; r++) um_load(R0, R1, plane, W, H, xc, row_of(0, r), fl[r], u[r]);
+#pragma unroll
+        for (int r = 0; r < 2; r++) fln[r] = ld_flow(flow_in + (size_t)row_of(1, r) * W + xc);
+    }
+
+    for (int g0 = 0; g0 < G; g0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int g = g0 + q;
+            if (g < G) {                                       // uniform
+                const int j = g - lag;
+                const bool act = j >= 0 && j < nst;            // wave-uniform
+                if (act) {
+                    float mi[2][5];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) um_math(u[r], W, H, xc, row_of(j, r), fl[r], mi[r]);
+                    if (j >= 8) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const int s_in = (2 * q + r) & 15, s_out = (2 * q + r + 1) & 15;
+#pragma unroll
+                            for (int ch = 0; ch < 5; ch++) {
+                                vs[stage][q & 1][ch][r][c] = v[ch];
+                                v[ch] += (double)mi[r][ch] - (double)ring[s_out][ch];
+                            }
+#pragma unroll
+                            for (int ch = 0; ch < 5; ch++) ring[s_in][ch] = mi[r][ch];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const int s_in = (2 * q + r) & 15;
+                            if (j > 0 || r > 0) {              // the very first row lies outside the first window
+#pragma unroll
+                                for (int ch = 0; ch < 5; ch++) v[ch] += (double)mi[r][ch];
+                            }
+#pragma unroll
+                            for (int ch = 0; ch < 5; ch++) ring[s_in][ch] = mi[r][ch];
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- operands of the next step: in flight during the horizontal pass ----
+                if (j + 1 >= 0 && j + 1 < nst) {
+                    if (stage == 0) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) fl[r] = fln[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) fl[r] = link[row_of(j + 1, r) & 15][cl];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) um_load(R0, R1, plane, W, H, xc, row_of(j + 1, r), fl[r], u[r]);
+                    if (stage == 0) {
+#pragma unroll
+                        for (int r = 0; r < 2; r++) fln[r] = ld_flow(flow_in + (size_t)row_of(j + 2, r) * W + xc);
+                    }
+                }
+                // ---- horizontal pass: 2 rows x C columns = NW waves x 64 lanes x 2 outputs ----
+                if (act && j >= 8) {
+                    const int item = 128 * wl + 2 * lane;
+                    const int r = item / C, t = item - r * C;          // outputs t, t+1 <-> centre columns t+M, t+M+1
+                    const int y = yb + 2 * (j - 8) + r;
+                    double S[5][2];
+#pragma unroll
+                    for (int ch = 0; ch < 5; ch++) {
+                        const double *base = &vs[stage][q & 1][ch][r][t];
+                        double a[16];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const double2 d = *reinterpret_cast<const double2 *>(base + 2 * k);
+                            a[2 * k] = d.x; a[2 * k + 1] = d.y;
+                        }
+                        double s = a[0];
+#pragma unroll
+                        for (int k = 1; k <= 2 * M; k++) s += a[k];
+                        S[ch][0] = s;
+                        s += a[2 * M + 1] - a[0];
+                        S[ch][1] = s;
+                    }
+                    float2 fo[2];
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                     h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        fo[o] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                    }
+                    if (stage == 0) {
+                        if (t < C - 2 * M && y < H) {
+                            link[y & 15][t + M] = fo[0];
+                            link[y & 15][t + M + 1] = fo[1];
+                        }
+                    } else if (y < y_end) {
+#pragma unroll
+                        for (int o = 0; o < 2; o++) {
+                            const int x = x0 - M + t + o;
+                            if (t + o >= M && t + o < C - 3 * M && x < W) st_flow(flow_out + (size_t)y * W + x, fo[o]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// strip height of the two-iteration kernel: rounds x (steps per strip), one work-group per CU
+int flow_iter2_rows(int W, int H, int npair, int winsize, int C)
+{
+    const int tiles_x = cdiv(W, C - 2 * (winsize - 1));
+    const int resident = 256;
+    int best_rows = cdiv(H, 2) * 2;
+    int64_t best_cost = LLONG_MAX;
+    for (int n = 1; n <= 64; n++) {
+        const int rows = cdiv(cdiv(H, n), 2) * 2;
+        if (rows < 16 && n > 1) break;
+        const int64_t blocks = (int64_t)tiles_x * cdiv(H, rows) * npair;
+        const int64_t cost = cdiv64(blocks, resident) * (FI2_LAG + 8 + rows / 2);
+        if (cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    return best_rows;
+}
+
+int launch_flow_iter2(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                      int H, int winsize, hipStream_t s, int rows_per_block)
+{
+    if (winsize != 15) { set_error("two-iteration kernel is built for winsize 15 only (got %d)", winsize); return OFC_EUNSUPPORTED; }
+    if ((int64_t)W * H * 5 >= (1ll << 30)) { set_error("frame too large for 32-bit R offsets (%dx%d)", W, H); return OFC_EUNSUPPORTED; }
+    constexpr int MM = 7, CC = 256;
+    if (rows_per_block <= 0) rows_per_block = flow_iter2_rows(W, H, npair, winsize, CC);
+    rows_per_block = cdiv(rows_per_block, 2) * 2;
+    const int tx = cdiv(W, CC - 4 * MM), ns = cdiv(H, rows_per_block);
+    dim3 grid(cdiv(tx * ns, 8) * 8 * npair);
+    hipLaunchKernelGGL((k_flow_iter2<MM, CC>), grid, dim3(2 * CC), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                       rows_per_block, tx, ns, npair);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6  flow upsample: resize(prevFlow, (w,h), INTER_LINEAR) * (1/pyr_scale).  10 B/px.  Bit-exact.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_resize(const float2 *__restrict__ src,

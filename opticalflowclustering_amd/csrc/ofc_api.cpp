@@ -224,6 +224,9 @@ struct ofc_flow {
     DevBuf I, R, M, flowA, flowB, flowC;   // scratch sized for level 0 and max_batch
     bool fused = true;              // update-matrices fused into the box/solve kernel (winsize <= 15)
     bool fuse_level0 = true;        // polyexp of level 0 reads the u8 frames (no f32 level-0 image)
+    bool fuse2 = false;             // iterations 2+3 of a level in one launch (k_flow_iter2): measured SLOWER than two launches
+                                    // on MI355X, kept as an opt-in experiment: OFC_FLOW_FUSE2=1 ...
+    int fuse2_min_w = 0;            // ... or OFC_FLOW_FUSE2=<N > 1>: only at pyramid levels at least N pixels wide
     DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
@@ -257,20 +260,30 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
         const size_t strideR = 5 * P;
         const float mul = (float)(1. / f->prm.pyr_scale);
         if (f->fused) {
-            // iteration i writes dst when (iters-1-i) is even, tmp otherwise; the first one reads the coarser
-            // level directly (upsample fused) or, at the top of the pyramid, a zeroed buffer
+            // launch plan: the first iteration alone (it reads the coarser level directly -- upsample fused -- or, at the
+            // top of the pyramid, a zeroed buffer), then two iterations per launch while the level is wide enough for the
+            // two-iteration kernel's 228-column tiles, single launches otherwise.  Launch l of L writes dst when (L-1-l)
+            // is even, tmp otherwise, so that the last one lands in dst.
+            const bool two = f->fuse2 && f->prm.winsize == 15 && g.w >= f->fuse2_min_w;
+            int plan[64], L = 0;
+            for (int i = 0; i < iters;) {
+                const int n = (two && i > 0 && iters - i >= 2) ? 2 : 1;
+                plan[L++] = n;
+                i += n;
+            }
             const float *cur = nullptr;
-            for (int i = 0; i < iters; i++) {
-                float *nxt = ((iters - 1 - i) & 1) ? tmp : dst;
-                if (i == 0 && prevFlow) {
+            for (int l = 0; l < L; l++) {
+                float *nxt = ((L - 1 - l) & 1) ? tmp : dst;
+                if (l == 0 && prevFlow) {
                     OFC_TRY(launch_flow_iter(R, strideR, nullptr, nxt, npair, g.w, g.h, f->prm.winsize, s, prevFlow, pw, ph, mul));
                 } else {
-                    if (i == 0) {
+                    if (l == 0) {
                         float *z = (nxt == dst) ? tmp : dst;
                         OFC_HIP(hipMemsetAsync(z, 0, sizeof(float) * 2 * P * npair, s));
                         cur = z;
                     }
-                    OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                    if (plan[l] == 2) OFC_TRY(launch_flow_iter2(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                    else OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
                 }
                 cur = nxt;
             }
@@ -322,6 +335,12 @@ int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_ba
         const char *e = getenv("OFC_FLOW_STAGED");      // debugging aid: force the separate K4 / K5 kernels
         f->fused = prm.winsize <= 15 && !(e && e[0] == '1');
         f->fuse_level0 = !(e && e[0] == '1');            // the staged mode also keeps the separate level-0 image
+        const char *e2 = getenv("OFC_FLOW_FUSE2");       // 1: two iterations per launch; N > 1: at levels >= N wide
+        if (e2 && e2[0]) {
+            const int v = atoi(e2);
+            f->fuse2 = v != 0;
+            if (v > 1) f->fuse2_min_w = v;
+        }
     }
     if (f->fused) {
         OFC_TRY(f->flowC.alloc(sizeof(float) * 2 * P0 * nb));
@@ -572,6 +591,76 @@ int ofc_flow_resize(int device, const float *flow, int sw, int sh, int dw, int d
     OFC_HIP(hipMemcpy(s.p, flow, sizeof(float) * 2 * sw * sh, hipMemcpyHostToDevice));
     OFC_TRY(launch_flow_resize(s.as<float>(), d.as<float>(), 1, sw, sh, dw, dh, mul, nullptr));
     OFC_HIP(hipMemcpy(out, d.p, sizeof(float) * 2 * dw * dh, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_flow_iterate(int device, const float *R0, const float *R1, const float *flow_in, int W, int H,
+                     int winsize, int iters, int mode, int rows_per_block, float *flow_out)
+{
+    OFC_REQUIRE(R0 && R1 && flow_in && flow_out, "null pointer");
+    OFC_REQUIRE(W >= 2 && H >= 2 && iters >= 1 && iters <= 64, "bad size / iteration count");
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    DevBuf dR, dA, dB;
+    OFC_TRY(dR.alloc(sizeof(float) * 10 * P));
+    OFC_TRY(dA.alloc(sizeof(float) * 2 * P));
+    OFC_TRY(dB.alloc(sizeof(float) * 2 * P));
+    OFC_HIP(hipMemcpy(dR.p, R0, sizeof(float) * 5 * P, hipMemcpyHostToDevice));
+    OFC_HIP(hipMemcpy(dR.as<float>() + 5 * P, R1, sizeof(float) * 5 * P, hipMemcpyHostToDevice));
+    OFC_HIP(hipMemcpy(dA.p, flow_in, sizeof(float) * 2 * P, hipMemcpyHostToDevice));
+    float *cur = dA.as<float>(), *nxt = dB.as<float>();
+    for (int i = 0; i < iters;) {
+        const int n = (mode == 1 && iters - i >= 2) ? 2 : 1;
+        if (n == 2) OFC_TRY(launch_flow_iter2(dR.as<float>(), 5 * P, cur, nxt, 1, W, H, winsize, nullptr, rows_per_block));
+        else OFC_TRY(launch_flow_iter(dR.as<float>(), 5 * P, cur, nxt, 1, W, H, winsize, nullptr));
+        std::swap(cur, nxt);
+        i += n;
+    }
+    OFC_HIP(hipMemcpy(flow_out, cur, sizeof(float) * 2 * P, hipMemcpyDeviceToHost));
+    return OFC_OK;
+}
+
+int ofc_bench_flow_iters(int device, int W, int H, int n_pairs, int reps, int mode, float *ms_out)
+{
+    OFC_REQUIRE(ms_out && n_pairs >= 1 && reps >= 1, "bad arguments");
+    OFC_TRY(ensure_device(device));
+    const size_t P = (size_t)W * H;
+    const int nf = n_pairs + 1;
+    PolyConsts pc;
+    polyexp_setup(5, 1.2, pc);
+    DevBuf fr, R, fa, fb;
+    OFC_TRY(fr.alloc(P * nf));
+    OFC_TRY(R.alloc(sizeof(float) * 5 * P * nf));
+    OFC_TRY(fa.alloc(sizeof(float) * 2 * P * n_pairs));
+    OFC_TRY(fb.alloc(sizeof(float) * 2 * P * n_pairs));
+    hipStream_t s;
+    OFC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    OFC_TRY(ofc_synth_frames_dev(device, fr.as<uint8_t>(), W, H, nf, 0, 0));
+    OFC_HIP(hipDeviceSynchronize());
+    OFC_TRY(launch_polyexp_u8(fr.as<uint8_t>(), R.as<float>(), nf, W, H, pc, s));
+    OFC_HIP(hipMemsetAsync(fb.p, 0, sizeof(float) * 2 * P * n_pairs, s));
+    // a realistic flow_in: one iteration from zero flow
+    OFC_TRY(launch_flow_iter(R.as<float>(), 5 * P, fb.as<float>(), fa.as<float>(), n_pairs, W, H, 15, s));
+    hipEvent_t e0, e1;
+    OFC_HIP(hipEventCreate(&e0));
+    OFC_HIP(hipEventCreate(&e1));
+    auto two = [&]() -> int {
+        if (mode == 1) return launch_flow_iter2(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s);
+        OFC_TRY(launch_flow_iter(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s));
+        // second iteration in place of the pair's scratch: fb -> fa would overwrite the input; write a third pass back to fb
+        return launch_flow_iter(R.as<float>(), 5 * P, fb.as<float>(), fa.as<float>(), n_pairs, W, H, 15, s);
+    };
+    OFC_TRY(two());
+    OFC_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; i++) OFC_TRY(two());
+    OFC_HIP(hipEventRecord(e1, s));
+    OFC_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    OFC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
     return OFC_OK;
 }
 

@@ -58,6 +58,23 @@ def flow_resize(flow, dw, dh, mul=1.0, device=0):
     return out
 
 
+def flow_iterate(R0, R1, flow_in, iters, winsize=15, mode=0, rows_per_block=0, device=0):
+    """`iters` Farneback iterations from flow_in with the engine's fused kernels (mode 1: two iterations per launch)"""
+    R0, R1, flow_in = (np.ascontiguousarray(a, np.float32) for a in (R0, R1, flow_in))
+    H, W = flow_in.shape[:2]
+    out = np.empty((H, W, 2), np.float32)
+    check(load().ofc_flow_iterate(device, ptr(R0), ptr(R1), ptr(flow_in), W, H, winsize, iters, mode, rows_per_block,
+                                  ptr(out)))
+    return out
+
+
+def bench_flow_iters(W, H, n_pairs, reps, mode, device=0):
+    """ms per batch for the last two iterations of a level (mode 0: two launches, mode 1: the two-iteration kernel)"""
+    ms = C.c_float()
+    check(load().ofc_bench_flow_iters(device, W, H, n_pairs, reps, mode, C.byref(ms)))
+    return ms.value
+
+
 def bench_polyexp(W, H, n_images, iters, rows_per_block=0, device=0):
     ms = C.c_float()
     check(load().ofc_bench_polyexp(device, W, H, n_images, iters, rows_per_block, C.byref(ms)))

@@ -259,3 +259,62 @@ def test_flow_other_parameters(name, kw, W, H):
     eng.close()
     assert rel(got, want) <= 1e-4, rel(got, want)
     assert np.abs(got - want).max() <= 1e-3, np.abs(got - want).max()
+
+
+# ---- the two-iteration kernel (k_flow_iter2): iterations 2+3 of a level in one launch ----
+def _iter_case(W, H, seed=0, dx=2.3, dy=-1.1):
+    a, b = synth.translated_pair(W, H, dx, dy)
+    R0, R1 = O.polyexp(O.level_image(a, 0)), O.polyexp(O.level_image(b, 0))
+    rng = np.random.default_rng(seed)
+    flow = (rng.standard_normal((H, W, 2)) * 1.5).astype(np.float32)
+    return R0, R1, flow
+
+
+def _oracle_iterations(R0, R1, flow, n, winsize=15):
+    """n x (update matrices -> box mean -> solve): oracle/farneback_ref.c's iteration loop unrolled"""
+    M = O.update_matrices(R0, R1, flow)
+    for i in range(n):
+        flow, M = O.update_flow_blur(R0, R1, flow, M, winsize, i < n - 1)
+    return flow
+
+
+@pytest.mark.parametrize("W,H,rows", [(480, 270, 0), (700, 96, 0), (229, 40, 0), (228, 18, 0), (1000, 300, 64),
+                                      (457, 131, 16), (64, 16, 0), (300, 17, 0)])
+def test_two_iteration_kernel_equals_two_single_launches(st, W, H, rows):
+    """same arithmetic per iteration; only the grouping of the f64 horizontal sums differs (2 outputs per lane instead of
+    4), so a flow value may differ in its last f32 bit once in a while"""
+    R0, R1, flow = _iter_case(W, H, seed=W)
+    one = st.flow_iterate(R0, R1, flow, 2, mode=0)
+    two = st.flow_iterate(R0, R1, flow, 2, mode=1, rows_per_block=rows)
+    assert np.isfinite(two).all()
+    d = np.abs(one - two)
+    assert d.max() <= 1e-6 * max(1.0, np.abs(one).max()), d.max()
+    assert (d == 0).mean() >= 0.999
+
+
+def test_two_iteration_kernel_against_oracle(st):
+    R0, R1, flow = _iter_case(480, 270, seed=3)
+    want = _oracle_iterations(R0, R1, flow, 2)
+    got = st.flow_iterate(R0, R1, flow, 2, mode=1)
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    # 4 iterations = two launches of the two-iteration kernel
+    want4 = _oracle_iterations(R0, R1, flow, 4)
+    got4 = st.flow_iterate(R0, R1, flow, 4, mode=1)
+    assert np.abs(got4 - want4).max() <= 5e-5 * max(1.0, np.abs(want4).max())
+
+
+def test_engine_with_and_without_two_iteration_kernel(monkeypatch):
+    """end to end at a size where the engine picks the two-iteration kernel at levels 0 and 1 (env-forced everywhere)"""
+    from opticalflowclustering_amd.flow import FlowEngine
+    W, H = 1000, 560
+    a, b = synth.translated_pair(W, H, 3.0, 1.5)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OFC_FLOW_FUSE2", mode)
+        eng = FlowEngine(W, H)
+        outs[mode] = eng.calc(a, b)
+        eng.close()
+    d = np.abs(outs["0"] - outs["1"])
+    assert d.max() <= 1e-5, d.max()
+    ref = O.farneback(a, b)
+    assert rel(outs["1"], ref) <= 1e-4 and np.abs(outs["1"] - ref).max() <= 1e-3
