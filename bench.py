@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the flow -> k-means hot path on MI355X.
 
-Workload (BASELINE.json configs[2]; configs[3] when launched on N > 1 GPUs): a 300-frame synthetic
+Default workload (BASELINE.json configs[2]; configs[3] when launched on N > 1 GPUs): a 300-frame synthetic
 1080p clip resident in HBM -> dense Farneback flow for all 299 consecutive pairs -> Lloyd's k-means
 (k=5, fixed init, max_iter=300, tol=1e-4, run to convergence) over the 6.2e8 per-pixel (u,v) vectors.
 One "step" = one full pass (flow + k-means) over the clip.  With N ranks the pairs are sharded
@@ -11,13 +11,17 @@ once per iteration.
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --workload cfg4            # configs[4] shape: 4K frames pushed from host memory, k=8 on cell flow
 
 Prints ONE JSON line on rank 0 (metric = Mpixels/s of flow+k-means, whole job), including
-  roofline     -- the polynomial-expansion kernel (24 B/px algorithmic) timed with HIP events on its own
-                  stream over 64 distinct resident 1080p images, against the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (C restatement, 1 thread) timed on a bounded sample of the same clip.
+  roofline     -- the polynomial-expansion kernel (24 B/px algorithmic) timed with HIP events on its own stream over 64
+                  distinct resident 1080p images, against the 8 TB/s HBM peak; sub-objects `flow_iter` (the kernel that
+                  dominates a step, 56 B/px) and `pipeline` (whole flow, staged 478 B/px and fused 267 B/px models)
+  cpu_baseline -- the CPU oracle timed on a bounded sample of the same clip: single thread and all host cores, plus
+                  scikit-learn's own KMeans when importable.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +36,17 @@ W, H, CLIP_FRAMES, K_CLUSTERS = 1920, 1080, 300, 5
 INIT = np.array([[-3.0, -3.0], [-1.5, 1.0], [0.0, 0.0], [1.5, -1.0], [3.0, 3.0]])
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 POLYEXP_BYTES_PER_PX = 24  # 4 B read + 5 x 4 B written per pixel per image
+FLOW_ITER_BYTES_PER_PX = 56   # SURVEY.md 8d fused iteration: R0 20 + R1 20 (gathered) + flow 8 in + 8 out
+STAGED_BYTES_PER_PX = 478     # whole Farneback per full-res pixel, staged kernels (the model priced against)
+FUSED_BYTES_PER_PX = 267      # M never stored, R computed once per frame
+MAX_BATCH = 32
+
+
+def auto_batch(n_pairs, max_batch=MAX_BATCH):
+    """equal batches of at most max_batch pairs: a 38-pair shard runs 19 + 19, never 32 + 6 (the tail batch's launches
+    cost almost what a full batch's cost)"""
+    n_batches = -(-n_pairs // max_batch)
+    return -(-n_pairs // n_batches)
 
 
 def main():
@@ -39,10 +54,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="frame pairs per flow launch sequence")
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per flow launch sequence (0 = equal batches <= 32)")
     ap.add_argument("--frames", type=int, default=CLIP_FRAMES, help="clip length (default = the named config)")
     ap.add_argument("--engines", type=int, default=2, help="flow engines (HIP streams) fed round-robin")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs outside the timed region")
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2")
+    ap.add_argument("--frames4k", type=int, default=200, help="frames pushed per step of --workload cfg4")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,11 +79,17 @@ def main():
 
     lib = _lib.load()
     device = local_rank if world > 1 else 0
+    if args.workload == "cfg4":
+        if world > 1:
+            sys.exit("--workload cfg4 is a single-GPU measurement (each GPU of a node would run its own stream)")
+        print(json.dumps(bench_cfg4(args, device)), flush=True)
+        return
     rank, world, barrier, allreduce_max = dist.init_from_torch_env(device)
 
     n_pairs_total = args.frames - 1
     p0, p1 = shard_pairs(n_pairs_total, world, rank)
-    pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=args.batch, device=device, n_engines=args.engines)
+    batch = args.batch if args.batch > 0 else auto_batch(p1 - p0)
+    pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=batch, device=device, n_engines=args.engines)
     pipe.synth(t0=p0, seed=0)
 
     def step():
@@ -84,15 +108,6 @@ def main():
     barrier()
     dt = allreduce_max(time.perf_counter() - t0)
     centers, inertia, n_iter = res
-    # extra, outside the timed region: the flow alone over the same resident clip (the configs[1] shape: many distinct
-    # 1080p pairs per launch sequence) -- reported as config.flow_only_mpx_s, not part of `value`
-    barrier()
-    tf = time.perf_counter()
-    for _ in range(2):
-        pipe.run_flow(sync=True)
-    barrier()
-    dt_flow = allreduce_max(time.perf_counter() - tf) / 2
-
     out = None
     if rank == 0:
         mpx = args.steps * n_pairs_total * W * H / 1e6
@@ -114,57 +129,245 @@ def main():
                                    % (2 if world == 1 else 3, args.frames, world),
                        "width": W, "height": H, "frames": args.frames, "pairs": n_pairs_total, "k": K_CLUSTERS,
                        "lloyd_iters": int(n_iter), "flow_batch_pairs": pipe.batch,
-                       "flow_only_mpx_s": n_pairs_total * W * H / 1e6 / dt_flow,
+                       "centers": [[float(v) for v in row] for row in centers], "inertia": float(inertia),
                        "parallelism": "frames sharded x%d, RCCL all-reduce of k*(d+1)+1 f64 per Lloyd iteration" % world},
         }
+    if not args.no_extras:
+        # ---- informational legs, outside the timed region ----
+        # (1) the flow alone over the same resident clip (the configs[1] shape: many distinct 1080p pairs per launch sequence)
+        barrier()
+        tf = time.perf_counter()
+        for _ in range(2):
+            pipe.run_flow(sync=True)
+        barrier()
+        dt_flow = allreduce_max(time.perf_counter() - tf) / 2
+        if rank == 0:
+            out["config"]["flow_only_mpx_s"] = n_pairs_total * W * H / 1e6 / dt_flow
+        # (2) the labelled, host-driven fit (sharded.fit_sharded over a DeviceShard: the form that reads and writes labels
+        # every iteration) over the resident flows must land where the label-less in-library fit did
+        if world == 1 and not force_dist:
+            out["config"]["labelled_fit_check"] = labelled_fit_check(pipe, centers, n_iter, device)
+    pipe.close()
+    if rank == 0 and world == 1 and not args.no_extras and args.frames == CLIP_FRAMES:
+        # (3) what one rank of an 8-GPU run does per step: its 38-pair shard of the same clip, alone on this GPU (no
+        # collective: RCCL refuses two ranks on one device) -- the number the >= 6x scaling target is priced on
+        out["config"]["shard_step_ms"] = shard_step_ms(device, args.engines)
+    if rank == 0:
         # ---- roofline leg: the polyexp kernel, HIP events on its own stream, 64 distinct 1080p images ----
         n_img, iters = 64, 20
         ms = stages.bench_polyexp(W, H, n_img, iters, 0, device)
         achieved = POLYEXP_BYTES_PER_PX * W * H * n_img / (ms * 1e-3) / 1e9
         out["roofline"] = {"kernel": "k_polyexp", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_polyexp"),
                            "launch_ms": ms, "images_per_launch": n_img,
                            "algorithmic_bytes_per_launch": POLYEXP_BYTES_PER_PX * W * H * n_img}
-        # ---- CPU baseline: the oracle (1 thread) on a bounded sample of the same clip ----
+        # the kernel that dominates a step (60 % of it): one level-0 Farneback iteration over 32 resident pairs
+        n_pairs_l = 32
+        ms_it = stages.bench_flow_iters(W, H, n_pairs_l, 10, 0, device) / 2
+        alg = FLOW_ITER_BYTES_PER_PX * W * H * n_pairs_l
+        out["roofline"]["flow_iter"] = {"kernel": "k_flow_iter<7,0>", "bound": "hbm",
+                                        "achieved": alg / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": pmc_traffic("k_flow_iter"), "launch_ms": ms_it,
+                                        "pairs_per_launch": n_pairs_l, "algorithmic_bytes_per_launch": alg}
+        if "flow_only_mpx_s" in out["config"]:
+            f = out["config"]["flow_only_mpx_s"] * 1e6
+            out["roofline"]["pipeline"] = {
+                "what": "whole Farneback flow (all levels, all kernels) over the resident clip, per full-res pixel",
+                "model": "staged (SURVEY.md 8d: 478 B/px, M stored, every kernel separate) is the one priced; the fused "
+                         "model (267 B/px: M never stored, R computed once per frame) is what the engine's kernels move",
+                "staged_bytes_per_px": STAGED_BYTES_PER_PX, "fused_bytes_per_px": FUSED_BYTES_PER_PX,
+                "achieved_staged": f * STAGED_BYTES_PER_PX / 1e9, "frac_staged": f * STAGED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
+                "achieved_fused": f * FUSED_BYTES_PER_PX / 1e9, "frac_fused": f * FUSED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        # ---- CPU baseline: the oracle on a bounded sample of the same clip ----
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(pipe, n_iter)
-    pipe.close()
+            out["cpu_baseline"] = cpu_baseline(device)
     if world > 1 or force_dist:
         dist.finalize()
     if rank == 0:
         print(json.dumps(out), flush=True)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/r01_polyexp_pmc.json:
-    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); counters cannot be read from inside
-    the benchmark process, so this is the recorded value for the same launch configuration, or null."""
+def labelled_fit_check(pipe, centers, n_iter, device):
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.sharded import DeviceShard, fit_sharded
+    N = pipe.n_pairs * W * H
+    shard = DeviceShard(pipe.flows.ptr, _lib.F32, N, 2, pipe.labels.ptr, device)
+    c2, _, it2 = fit_sharded(shard, INIT, max_iter=300, tol=1e-4)
+    ok = int(it2) == int(n_iter) and float(np.abs(c2 - centers).max()) <= 1e-9
+    return {"ok": bool(ok), "n_iter": [int(n_iter), int(it2)], "max_abs_centre_diff": float(np.abs(c2 - centers).max())}
+
+
+def shard_step_ms(device, engines, steps=10):
+    """one rank's share of configs[3]: pairs [0, 38) of the clip, flow + Lloyd to convergence over its own vectors"""
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.pipeline import ClipPipeline, shard_pairs
+    p0, p1 = shard_pairs(CLIP_FRAMES - 1, 8, 0)
+    pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=auto_batch(p1 - p0), device=device, n_engines=engines)
+    pipe.synth(t0=p0, seed=0)
+    lib = _lib.load()
+    for _ in range(2):
+        pipe.run_flow(sync=False)
+        pipe.run_kmeans(INIT, max_iter=300, tol=1e-4)
+    _lib.check(lib.ofc_device_sync(device))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run_flow(sync=False)
+        pipe.run_kmeans(INIT, max_iter=300, tol=1e-4)
+    _lib.check(lib.ofc_device_sync(device))
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    pipe.close()
+    return ms
+
+
+def source_sha16():
+    """fingerprint of the kernel sources a recorded PMC pass belongs to"""
+    h = hashlib.sha256()
+    for name in ("flow_kernels.hip",):
+        with open(os.path.join(ROOT, "opticalflowclustering_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside the benchmark process, so this is the
+    value recorded for the same launch configuration -- and only while the kernel source is the one the passes were
+    collected on (sha of flow_kernels.hip recorded beside them); otherwise null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_polyexp_pmc.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            rec = json.load(f)
+        if rec.get("source_sha16") != source_sha16():
+            return None
+        return rec["kernels"][kernel]["traffic_bytes_per_launch"]
     except Exception:
         return None
 
 
-def cpu_baseline(pipe, n_iter, sample_pairs=16):
-    """the CPU restatement of the same path (oracle/, C, single thread) on the first `sample_pairs`
-    pairs of the clip: Farneback per pair, then Lloyd (same init, to convergence) over their (u,v)"""
+def cpu_baseline(device, single_pairs=4, multi_pairs=32):
+    """the CPU restatement of the same path (oracle/*.c) on the first pairs of the same clip, built -O3 -march=native on
+    this host: (a) ONE thread, `single_pairs` pairs (how OpenCV's serial row loops and a 1-thread sklearn would run);
+    (b) ALL host cores this process may use, `multi_pairs` pairs: Farneback per pair on a thread pool (pairs are
+    independent), Lloyd with the samples split over the threads and the partial sums added per iteration (the shape of
+    sklearn's OpenMP chunks); (c) scikit-learn's own KMeans on the same vectors when it is importable here."""
+    from concurrent.futures import ThreadPoolExecutor
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    from opticalflowclustering_amd.sharded import fit_sharded
     from oracle import oracle as O
     P = W * H
-    frames = pipe.frames.download((sample_pairs + 1, H, W), np.uint8)
+    pipe = ClipPipeline(W, H, multi_pairs + 1, batch_pairs=multi_pairs, device=device, n_engines=1)
+    pipe.synth(t0=0, seed=0)
+    frames = pipe.frames.download((multi_pairs + 1, H, W), np.uint8)
+    pipe.close()
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    N = O.native()                                      # -O3 -march=native build of the same C files, made here
+    # ---- (a) one thread ----
     t0 = time.perf_counter()
-    flows = np.stack([O.farneback(frames[t], frames[t + 1]) for t in range(sample_pairs)])
-    t_flow = time.perf_counter() - t0
-    X = flows.reshape(-1, 2)
-    t1 = time.perf_counter()
-    _, _, _, it = O.kmeans_fit(X, INIT)
-    t_km = time.perf_counter() - t1
-    cores = 1
-    return {"value": sample_pairs * P / 1e6 / (t_flow + t_km), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "first %d pairs of the clip (%d x 1080p): flow %.2f s + Lloyd k=5 %d iters %.2f s, "
-                      "oracle/*.c built -O2 without -march=native, 1 thread"
-                      % (sample_pairs, sample_pairs, t_flow, it, t_km),
-            "host_cores_available": os.cpu_count()}
+    flows1 = np.stack([N.farneback(frames[t], frames[t + 1]) for t in range(single_pairs)])
+    t_flow1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, _, _, it1 = N.kmeans_fit(flows1.reshape(-1, 2), INIT)
+    t_km1 = time.perf_counter() - t0
+    single = {"value": single_pairs * P / 1e6 / (t_flow1 + t_km1), "unit": "Mpixels/s", "cores": 1,
+              "sample": "first %d pairs: flow %.2f s + Lloyd k=5 %d iterations %.2f s" % (single_pairs, t_flow1, it1, t_km1)}
+    # ---- (b) all cores ----
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        flows = np.stack(list(pool.map(lambda t: N.farneback(frames[t], frames[t + 1]), range(multi_pairs))))
+        t_flow = time.perf_counter() - t0
+        X = flows.reshape(-1, 2)
+        shard = ThreadedOracleShard(X, cores, pool, N)
+        t0 = time.perf_counter()
+        _, _, it = fit_sharded(shard, INIT, max_iter=300, tol=1e-4)
+        t_km = time.perf_counter() - t0
+    allc = {"value": multi_pairs * P / 1e6 / (t_flow + t_km), "unit": "Mpixels/s", "cores": cores,
+            "sample": "first %d pairs: flow %.2f s + Lloyd k=5 %d iterations %.2f s, %d threads" % (multi_pairs, t_flow, it, t_km, cores)}
+    # ---- (c) the reference's own Lloyd ----
+    try:
+        import warnings
+        from sklearn.cluster import KMeans
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            km = KMeans(n_clusters=K_CLUSTERS, init=INIT, n_init=1, max_iter=300, tol=1e-4).fit(X)
+        t_sk = time.perf_counter() - t0
+        import sklearn
+        sk = {"value": len(X) / 1e6 / t_sk, "unit": "Mpoints/s (Lloyd only)", "seconds": t_sk, "n_iter": int(km.n_iter_),
+              "version": sklearn.__version__, "sample": "the %d (u,v) vectors of (b), f32 as the flow produces them" % len(X)}
+    except Exception as e:                              # not importable on this box
+        sk = "unavailable on this box (%s)" % e.__class__.__name__
+    return {"value": allc["value"], "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": allc["sample"] + "; oracle/*.c built -O3 -march=native on this host",
+            "single_thread": single, "all_cores": allc, "sklearn_kmeans": sk, "host_cores_available": os.cpu_count()}
+
+
+class ThreadedOracleShard:
+    """the four shard-local passes of sharded.fit_sharded on the CPU oracle, rows split over a thread pool"""
+
+    def __init__(self, X, n, pool, N):
+        self.X, self.pool, self.Nlib = X, pool, N
+        self.N, self.d = X.shape
+        self.cuts = [(self.N * i) // n for i in range(n + 1)]
+        self.labels = np.full(self.N, -1, np.int32)
+
+    def _map(self, fn):
+        return list(self.pool.map(lambda i: fn(self.cuts[i], self.cuts[i + 1]), range(len(self.cuts) - 1)))
+
+    def colstats(self, mean, pass_):
+        if pass_ == 0:
+            return np.sum(self._map(lambda a, b: self.X[a:b].astype(np.float64).sum(0)), 0)
+        return np.sum(self._map(lambda a, b: ((self.X[a:b].astype(np.float64) - mean) ** 2).sum(0)), 0)
+
+    def step(self, mean, centers_c, accumulate=True):
+        return np.sum(self._map(lambda a, b: self.Nlib.lloyd_partials(self.X[a:b], mean, centers_c, self.labels[a:b])), 0)
+
+    def inertia(self, mean, centers_c):
+        return float(np.sum(self._map(lambda a, b: ((self.X[a:b].astype(np.float64) - mean - centers_c[self.labels[a:b]]) ** 2).sum())))
+
+    def farthest(self, mean, centers_c, excl):
+        Xc = self.X.astype(np.float64) - mean
+        d2 = ((Xc - centers_c[self.labels]) ** 2).sum(1)
+        d2[list(excl)] = -2
+        i = int(np.argmax(d2))
+        return float(d2[i]), i, Xc[i], int(self.labels[i])
+
+
+def bench_cfg4(args, device):
+    """BASELINE.json configs[4] on one GPU: 4K frames pushed one by one from host memory (as a decoder hands them over)
+    through the pinned double-buffered hipMemcpyAsync ingest, Farneback per pair, reduced on the device to the 14x25
+    grid-cell averaged flow (KmeanGrids' grid), then Lloyd k=8 over the cell vectors.  PCIe-inclusive by construction."""
+    from opticalflowclustering_amd import synth
+    from opticalflowclustering_amd.cluster import KMeans
+    from opticalflowclustering_amd.stream import FlowStream
+    W4, H4, n = 3840, 2160, args.frames4k
+    p = synth.texture_params(0)
+    base = [synth.frame(W4, H4, 0.9 * t, -0.5 * t, p).astype(np.uint8) for t in range(8)]
+    fs = FlowStream(W4, H4, batch_pairs=8, device=device)
+
+    def step():
+        for t in range(n):
+            fs.push(base[t % 8])
+        cells = fs.finish()
+        km = KMeans(n_clusters=8, init="seeded-rows", random_state=0, device=device).fit(cells.reshape(-1, 2))
+        return cells, km
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cells, km = step()
+    dt = time.perf_counter() - t0
+    fs.close()
+    return {"metric": "Mpixels/s dense flow+kmeans @4K stream", "value": args.steps * (n - 1) * W4 * H4 / 1e6 / dt,
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage, f64 accumulation", "data": "synthetic, pushed from host memory (PCIe-inclusive)",
+            "config": {"workload": "BASELINE.json configs[4] on one GPU: %d-frame 4K stream, pinned double-buffered ingest, "
+                                   "Farneback, 14x25 grid-cell averaged flow, Lloyd k=8 over the cell vectors" % n,
+                       "width": W4, "height": H4, "frames": n, "pairs": n - 1, "k": 8, "lloyd_iters": int(km.n_iter_),
+                       "cell_vectors": int(cells.shape[0] * cells.shape[1]), "ms_per_frame": 1e3 * dt / args.steps / n,
+                       "upload_bytes_per_frame": W4 * H4}}
 
 
 if __name__ == "__main__":

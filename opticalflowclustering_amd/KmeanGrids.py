@@ -20,6 +20,7 @@ import os
 
 import numpy as np
 
+from . import seeding
 from ._lib import check, load, ptr
 from .computeOpticalFlowModule import ComputeOpticalFLow
 from .frameio import FrameSource, get_number  # noqa: F401  (get_number re-exported like the reference)
@@ -65,19 +66,47 @@ def overlayGridAndComputeAvgColor(framNum, frame, grid_params, csv_file=None, in
     return avg_bgr, avg_hsv
 
 
-def cluster_frame_cells(compflow, n_clusters, grid_params=GRID_PARAMS, device=0, max_iter=300, tol=1e-4):
+def cell_problems(frame_bgr, grid_params=GRID_PARAMS, device=0):
+    """the 350 k-means problems of one visualisation frame as the reference forms them (KmeanGrids.py:108-113, 269-286):
+    cells cut from the frame AFTER cv2.rectangle drew the white grid lines, then preprocess_image -> (n, 4) uint8 rows.
+    Only needed to seed the fits on the host (--init k-means++ / seeded-rows); the fits themselves read the
+    device-resident frame."""
+    from .color_kmeans import preprocess_image
+    rows, cols = grid_params["rows"], grid_params["cols"]
+    x_step, y_step = grid_geometry(frame_bgr.shape, grid_params)
+    cells = np.empty((rows * cols, y_step, x_step, 3), np.uint8)
+    for y in range(rows):
+        for x in range(cols):
+            x1, y1 = x * x_step, y * y_step
+            cell = cells[y * cols + x]
+            cell[...] = frame_bgr[y1:y1 + y_step, x1:x1 + x_step]
+            cell[0, :] = 255          # what the stored cell holds (App. D.5): its own top / left grid line; the bottom /
+            cell[:, 0] = 255          # right lines are drawn later and belong to the next cells (lloyd_batched.hip loader)
+    rgba = preprocess_image(cells.reshape(rows * cols * y_step, x_step, 3), device)      # one launch for all cells
+    return list(rgba.reshape(rows * cols, y_step * x_step, 4))
+
+
+def cluster_frame_cells(compflow, n_clusters, grid_params=GRID_PARAMS, device=0, max_iter=300, tol=1e-4,
+                        init="maximin", seed=0, frame_bgr=None):
     """KmeanGrids.py:382-392 for the frame compute() just produced, on the device-resident visualisation:
-    -> (rint'ed dominant centres (350,4), hsv (350,3) uint8)"""
+    -> (rint'ed dominant centres (350,4), hsv (350,3) uint8).  init other than 'maximin' seeds every cell's fit on the
+    host from `frame_bgr` (the array compute() returned) the way KMeans(n_clusters=k) would for that seed (:300)."""
     rows, cols = grid_params["rows"], grid_params["cols"]
     nc = rows * cols
     centers = np.empty((nc, 4), np.float64)
     hsv = np.empty((nc, 3), np.uint8)
+    init_arr = None
+    if init != "maximin" and n_clusters > 1:
+        if frame_bgr is None:
+            raise ValueError("seeding on the host needs the frame compute() returned")
+        init_arr = np.ascontiguousarray(seeding.batched_init(cell_problems(frame_bgr, grid_params, device), n_clusters,
+                                                             init, seed, device))
     check(load().ofc_grid_kmeans_dev(device, C.c_void_p(compflow.vis_device_ptr()), compflow.width, compflow.height, 1,
-                                     rows, cols, n_clusters, None, max_iter, tol, 0, ptr(centers), ptr(hsv)))
+                                     rows, cols, n_clusters, ptr(init_arr), max_iter, tol, 0, ptr(centers), ptr(hsv)))
     return centers, hsv
 
 
-def process_video(inputVideoFile, n_clusters, out_csv, device=0, quiet=False, store_cells=False):
+def process_video(inputVideoFile, n_clusters, out_csv, device=0, quiet=False, store_cells=False, init="maximin", seed=0):
     """KmeanGrids.py:149-239 + :376-401 fused into one streaming loop; returns the list of hue rows"""
     cap = FrameSource(inputVideoFile)
     ret, frame = cap.read()                                                 # :171
@@ -93,7 +122,8 @@ def process_video(inputVideoFile, n_clusters, out_csv, device=0, quiet=False, st
             break
         frame_optical = compflow.compute(frame_rgb)                         # :187
         frameNum += 1                                                       # :189 (first row is "frame 2")
-        _, hsv = cluster_frame_cells(compflow, n_clusters, device=device)   # :382-392
+        _, hsv = cluster_frame_cells(compflow, n_clusters, device=device, init=init, seed=seed,
+                                     frame_bgr=frame_optical)               # :382-392
         if store_cells:
             overlayGridAndComputeAvgColor(frameNum, frame_optical, GRID_PARAMS, device=device)   # :230-231
         hues = [int(h) for h in hsv[:, 0]]
@@ -117,7 +147,7 @@ def parse_arguments(argv=None):
     ap.add_argument("--noyolo", action="store_false", help="do not load yolo bounding boxes")
     ap.add_argument("--nocontour", action="store_false", help="do not use contour detection")
     ap.add_argument("--path", required=True, help="Path to the input video")
-    ap.add_argument("--device", type=int, default=0)
+    seeding.add_arguments(ap, "maximin")
     return vars(ap.parse_args(argv))
 
 
@@ -127,7 +157,7 @@ def main(argv=None):
     parts = str(dirs).replace("\\", "/").rstrip("/").split("/")
     name = parts[1] if len(parts) > 1 else parts[0]                         # :379 dirs.split('/')[1]
     filepathcsv = os.path.join("OutCSV", name + ".csv")                     # :377-379
-    process_video(args["path"], args["clusters"], filepathcsv, device=args["device"])
+    process_video(args["path"], args["clusters"], filepathcsv, device=args["device"], init=args["init"], seed=args["seed"])
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ Reference lines: color_kmeans.py:14-145.  All pixel arithmetic runs on the MI355
 
 Conscious deviations:
   * KMeans seeding is deterministic ('seeded-rows', seed 0) instead of unseeded k-means++ (D.8);
-    irrelevant for the documented k=1.
+    irrelevant for the documented k=1.  `--init k-means++ --seed N` gives sklearn's seeding for RandomState(N).
   * the CSV header is written when the OUTPUT csv is empty; the reference stats a hard-coded
     'cluster_centers.csv' in the CWD and raises if it is absent (D.2)."""
 import argparse
@@ -15,6 +15,7 @@ import os
 import numpy as np
 
 from ._lib import check, load, ptr
+from . import seeding
 from .cluster import KMeans
 from .frameio import imread_bgr
 
@@ -24,6 +25,7 @@ def parse_arguments(argv=None):
     ap.add_argument("-i", "--image", required=True, help="Path to the image")
     ap.add_argument("-c", "--clusters", required=True, type=int, help="# of clusters")
     ap.add_argument("-f", "--csv", required=True, type=str, help="# of clusters")
+    seeding.add_arguments(ap, "seeded-rows")
     return vars(ap.parse_args(argv))
 
 
@@ -69,9 +71,11 @@ def dominant_cluster(image_rgba, n_clusters, device=0, init="seeded-rows", rando
     return cluster0, hsv0, clt
 
 
-def cluster_colors(image, n_clusters, image_path, csv_file, device=0):
+def cluster_colors(image, n_clusters, image_path, csv_file, device=0, init="seeded-rows", random_state=0):
     """color_kmeans.py:54-135"""
-    cluster0, hsv0, _ = dominant_cluster(image, n_clusters, device)
+    if init == "maximin":
+        raise ValueError("--init maximin is the batched (grid) kernel's device-side seeding; use seeded-rows or k-means++")
+    cluster0, hsv0, _ = dominant_cluster(image, n_clusters, device, init, random_state)
     with open(csv_file, "a", newline="") as file:
         writer = csv.writer(file)
         if os.stat(csv_file).st_size == 0:
@@ -84,9 +88,9 @@ def main(argv=None):
     args = parse_arguments(argv)
     image = read_image(args["image"])
     print("\n\n\n Image Name", args["image"])
-    processed_image = preprocess_image(image)
+    processed_image = preprocess_image(image, args["device"])
     print("Dimensions", processed_image.ndim)
-    cluster_colors(processed_image, args["clusters"], args["image"], args["csv"])
+    cluster_colors(processed_image, args["clusters"], args["image"], args["csv"], args["device"], args["init"], args["seed"])
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 
+from . import seeding
 from .color_kmeans import bgr2hsv_pixel, read_image
 from .frameio import get_number
 from .vis import kmeans_fit_batched
@@ -20,6 +21,7 @@ def parse_arguments(argv=None):
     ap.add_argument("-d", "--dir", required=True, help="Path to the image")
     ap.add_argument("-c", "--clusters", required=True, type=int, help="# of clusters")
     ap.add_argument("-f", "--csv", required=True, type=str, help="# of clusters")
+    seeding.add_arguments(ap, "maximin")
     return vars(ap.parse_args(argv))
 
 
@@ -31,12 +33,13 @@ def preprocess_rows(image_rgb):
     return preprocess_image(image_rgb.copy()).reshape(-1, 4)
 
 
-def process_folder(folder, n_clusters, device=0):
+def process_folder(folder, n_clusters, device=0, init="maximin", seed=0):
     """all PNG cells of one frame folder -> list of (name, rint(top centre), hsv 1x1x3)"""
     names = sorted([n for n in os.listdir(folder) if not n.startswith(".")], key=get_number)
     rows = [preprocess_rows(read_image(os.path.join(folder, n))) for n in names]
     offsets = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
-    centers, counts, _, _ = kmeans_fit_batched(np.concatenate(rows), offsets, n_clusters, None, device=device)
+    init_arr = seeding.batched_init(rows, n_clusters, init, seed, device)        # KMeans(n_clusters=k) per cell (:66)
+    centers, counts, _, _ = kmeans_fit_batched(np.concatenate(rows), offsets, n_clusters, init_arr, device=device)
     out = []
     for p, n in enumerate(names):
         dom = int(np.argmax(counts[p]))                     # stable: first maximum, as sorted(..., reverse=True)
@@ -51,7 +54,8 @@ def main(argv=None):
     with open(args["csv"], "a", newline="") as file:
         writer = csv.writer(file)
         for contentFolder in sorted([d for d in os.listdir(dirs) if not d.startswith(".")], key=get_number):
-            for name, c0, hsv0 in process_folder(os.path.join(dirs, contentFolder), args["clusters"]):
+            for name, c0, hsv0 in process_folder(os.path.join(dirs, contentFolder), args["clusters"], args["device"],
+                                                 args["init"], args["seed"]):
                 writer.writerow([contentFolder + "/" + name, c0, hsv0, hsv0[0][0][0]])
             print(contentFolder)
 

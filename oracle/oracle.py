@@ -52,6 +52,43 @@ def lib():
     return _lib
 
 
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+
+
+class _Native:
+    """the same C files built -O3 -march=native ON THE HOST THAT RUNS THIS (bench.py's cpu_baseline leg): never shipped,
+    never built ahead of time (oracle/_native/ is git- and gpurun-ignored: a -march=native object must not travel)."""
+
+    def __init__(self):
+        os.makedirs(_NATIVE_DIR, exist_ok=True)
+        so = os.path.join(_NATIVE_DIR, "libofc_oracle_native.so")
+        srcs = [os.path.join(_HERE, f) for f in ("farneback_ref.c", "lloyd_ref.c", "color_ref.c")]
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
+                               "-o", so] + srcs + ["-lm"])
+        self._lib = C.CDLL(so)
+        for f in ("ofc_ref_farneback", "ofc_ref_kmeans_fit", "ofc_ref_lloyd_partials"):
+            getattr(self._lib, f).restype = C.c_int
+
+    def farneback(self, prev, nxt, params=None):
+        return farneback(prev, nxt, params, _lib=self._lib)
+
+    def kmeans_fit(self, X, init, max_iter=300, tol=1e-4):
+        return kmeans_fit(X, init, max_iter, tol, _lib=self._lib)
+
+    def lloyd_partials(self, X, mean, centers_c, labels):
+        return lloyd_partials(X, mean, centers_c, labels, _lib=self._lib)
+
+
+_native = None
+
+
+def native():
+    global _native
+    if _native is None:
+        _native = _Native()
+    return _native
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -149,14 +186,14 @@ def level_image(gray, k, params=None):
     return out
 
 
-def farneback(prev, nxt, params=None):
+def farneback(prev, nxt, params=None, _lib=None):
     """cv2.calcOpticalFlowFarneback(prev, next, None, 0.5, 3, 15, 3, 5, 1.2, 0) -> HxWx2 f32"""
     p = params or default_params()
     prev, nxt = _u8(prev), _u8(nxt)
     assert prev.shape == nxt.shape and prev.ndim == 2
     H, W = prev.shape
     flow = np.empty((H, W, 2), np.float32)
-    rc = lib().ofc_ref_farneback(_p(prev), _p(nxt), W, H, C.byref(p), _p(flow))
+    rc = (_lib or lib()).ofc_ref_farneback(_p(prev), _p(nxt), W, H, C.byref(p), _p(flow))
     if rc != 0:
         raise ValueError("oracle farneback: unsupported parameters")
     return flow
@@ -229,7 +266,7 @@ def preprocess_rgba(img3, thresh=30):
 _DT = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
 
 
-def kmeans_fit(X, init, max_iter=300, tol=1e-4):
+def kmeans_fit(X, init, max_iter=300, tol=1e-4, _lib=None):
     """-> centers (k,d) f64, labels (N,) i32, inertia, n_iter"""
     X = np.ascontiguousarray(X)
     if X.dtype not in _DT:
@@ -241,7 +278,7 @@ def kmeans_fit(X, init, max_iter=300, tol=1e-4):
     labels = np.empty(N, np.int32)
     inertia = C.c_double()
     n_iter = C.c_int()
-    rc = lib().ofc_ref_kmeans_fit(_p(X), _DT[X.dtype], C.c_int64(N), d, k, _p(init), max_iter,
+    rc = (_lib or lib()).ofc_ref_kmeans_fit(_p(X), _DT[X.dtype], C.c_int64(N), d, k, _p(init), max_iter,
                                   C.c_double(tol), _p(centers), _p(labels), C.byref(inertia),
                                   C.byref(n_iter))
     if rc != 0:
@@ -261,7 +298,7 @@ def kmeans_predict(X, centers):
     return labels
 
 
-def lloyd_partials(X, mean, centers_c, labels):
+def lloyd_partials(X, mean, centers_c, labels, _lib=None):
     """shard step: labels (i32, in/out). -> [sums k*d | counts k | n_changed]"""
     X = np.ascontiguousarray(X)
     mean = np.ascontiguousarray(mean, np.float64)
@@ -269,7 +306,7 @@ def lloyd_partials(X, mean, centers_c, labels):
     N, d = X.shape
     k = centers_c.shape[0]
     out = np.empty(k * d + k + 1, np.float64)
-    lib().ofc_ref_lloyd_partials(_p(X), _DT[X.dtype], C.c_int64(N), d, k, _p(mean),
+    (_lib or lib()).ofc_ref_lloyd_partials(_p(X), _DT[X.dtype], C.c_int64(N), d, k, _p(mean),
                                  _p(centers_c), _p(labels), _p(out))
     return out
 

@@ -81,6 +81,12 @@ def main():
     # empty-cluster relocation: one init centre far away from all data
     C0 = np.array([[0.0, 0.0], [1.0, 1.0], [500.0, 500.0]])
     run("reloc_f64_k3", B[:4096].astype(np.float64), C0, S)
+    # several empty clusters in one iteration (sklearn hands far points to empty clusters in argpartition order; the C
+    # oracle, lloyd_api.cpp and sharded.py go farthest-first: these pin that the two agree): 2 and 3 far-away centres
+    C0 = np.array([[0.0, 0.0], [1.0, 1.0], [500.0, 500.0], [-400.0, 300.0]])
+    run("reloc2_f64_k4", B[:4096].astype(np.float64), C0, S)
+    C0 = np.array([[0.5, -0.5], [-1.0, 0.3], [600.0, 0.0], [0.0, -700.0], [-300.0, -300.0], [1.5, 1.5]])
+    run("reloc3_f32_k6", B[4096:12288], C0, S)
     # f64 data, d=4, k=8
     D = rng.standard_normal((8192, 4)) * np.array([1, 2, 3, 4.0])
     run("gauss_f64_d4_k8", D, D[:8], S)

@@ -310,3 +310,172 @@ def test_color_kmeans_script_equals_per_file_runs(tmp_path):
         color_kmeans.main(["-i", str(d / n), "-c", "1", "-f", b])
     assert open(a).read() == open(b).read()
     assert len(open(a).read().splitlines()) == 8
+
+
+def _per_file_rows(d, csv_path, k, extra=()):
+    from opticalflowclustering_amd import color_kmeans
+    for n in sorted(os.listdir(d)):
+        if os.path.isfile(os.path.join(d, n)) and n.lower().endswith(".png"):
+            color_kmeans.main(["-i", str(os.path.join(d, n)), "-c", str(k), "-f", csv_path, *extra])
+
+
+def test_color_kmeans_script_survives_bad_entries_and_large_images(tmp_path, capsys):
+    """the reference's image folders hold 270x232 ... 370x280 crops (more points than the LDS-resident batched kernel
+    takes) and a `cropped/` sub-directory that "$IMAGES_DIR"/* also globs: the shell loop loses only that entry's row"""
+    from opticalflowclustering_amd import color_kmeans_script
+    from opticalflowclustering_amd.frameio import imwrite_bgr
+    rng = np.random.default_rng(3)
+    d = tmp_path / "imgs"
+    (d / "cropped").mkdir(parents=True)
+    (d / "notes.txt").write_text("not an image")
+    for i, (h, w) in enumerate([(40, 50), (232, 270), (33, 47), (280, 370)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[rng.random((h, w)) < 0.5] = 0
+        imwrite_bgr(str(d / f"{i:04d}.png"), img)
+    a, b = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    assert color_kmeans_script.main([str(d), a]) == 0
+    err = capsys.readouterr().err
+    assert "cropped" in err and "notes.txt" in err
+    _per_file_rows(str(d), b, 1)
+    assert open(a).read() == open(b).read()
+    assert len(open(a).read().splitlines()) == 5              # header + the four images, in glob order
+
+
+@pytest.mark.parametrize("extra", [(), ("--init", "k-means++", "--seed", "4")])
+def test_color_kmeans_script_k3_equals_per_file_runs(tmp_path, extra):
+    """-c 3: every image is seeded as `color_kmeans.py -c 3` seeds it, so the batched rows equal the per-file rows"""
+    from opticalflowclustering_amd import color_kmeans_script
+    from opticalflowclustering_amd.frameio import imwrite_bgr
+    rng = np.random.default_rng(21)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(5):
+        img = rng.integers(0, 256, (36 + i, 44, 3), dtype=np.uint8)
+        img[rng.random(img.shape[:2]) < 0.4] = 0
+        imwrite_bgr(str(d / f"{i:04d}.png"), img)
+    big = rng.integers(0, 256, (200, 180, 3), dtype=np.uint8)           # 36 000 points: the streaming path
+    imwrite_bgr(str(d / "0099.png"), big)
+    a, b = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    assert color_kmeans_script.main([str(d), a, "-c", "3", *extra]) == 0
+    _per_file_rows(str(d), b, 3, extra)
+    assert open(a).read() == open(b).read()
+
+
+KATKPP = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_kpp_goldens.npz"))
+
+
+def test_seeded_kmeans_plusplus_on_reference_cells_matches_sklearn(tmp_path):
+    """KMeans(n_clusters=3) as the reference constructs it (KmeanGrids.py:300, color_kmeans.py:66) plus a seed, on cells
+    of the reference's recorded visualisation; goldens from sklearn (make_kat_kpp_goldens.py).  Three routes: the
+    KMeans class, the batched kernel fed by seeding.batched_init, and the color_kmeansChange CLI with --init/--seed."""
+    from PIL import Image
+    from opticalflowclustering_amd import color_kmeansChange, seeding
+    from opticalflowclustering_amd.cluster import KMeans
+    from opticalflowclustering_amd.vis import kmeans_fit_batched
+    k, seed = int(KATKPP["k"]), int(KATKPP["seed"])
+    cells = [int(c) for c in KATKPP["cell_index"]]
+    problems = [O.preprocess_rgba(K["cells_rgb"][0][c]).reshape(-1, 4) for c in cells]
+    for j, X in enumerate(problems[:8]):
+        km = KMeans(n_clusters=k, init="k-means++", random_state=seed).fit(X)
+        assert km.n_iter_ == int(KATKPP["n_iter"][j])
+        assert np.abs(km.cluster_centers_ - KATKPP["centers"][j]).max() <= 1e-9
+    init = seeding.batched_init(problems, k, "k-means++", seed)
+    offsets = np.concatenate([[0], np.cumsum([len(p) for p in problems])]).astype(np.int64)
+    cen, counts, _, n_iter = kmeans_fit_batched(np.concatenate(problems), offsets, k, init)
+    assert np.array_equal(n_iter, KATKPP["n_iter"])
+    assert np.abs(cen - KATKPP["centers"]).max() <= 1e-9
+    d = tmp_path / "OutImgs" / "vid" / "2"
+    d.mkdir(parents=True)
+    for c in cells:
+        Image.fromarray(K["cells_rgb"][0][c]).save(d / f"{c + 1}.png")
+    out = str(tmp_path / "o.csv")
+    color_kmeansChange.main(["-d", str(tmp_path / "OutImgs" / "vid"), "-c", str(k), "-f", out,
+                             "--init", "k-means++", "--seed", str(seed)])
+    rows = list(csv.reader(open(out)))
+    assert [r[0] for r in rows] == [f"2/{c + 1}.png" for c in cells]
+    for j, r in enumerate(rows):
+        dom = KATKPP["dominant_rint"][j]
+        assert r[1] == str(dom), (r[1], dom)
+        assert int(r[3]) == int(O.bgr2hsv(dom[:3].astype(np.uint8).reshape(1, 1, 3))[0, 0, 0])
+
+
+def test_kmean_grids_seeded_init_equals_per_cell_fits(tmp_path, monkeypatch):
+    """KmeanGrids -c 3 --init k-means++ --seed 2: every cell's hue is what a KMeans(n_clusters=3, random_state=2) fit of
+    that cell (cut from the frame compute() returned, reference quirks included) gives"""
+    from opticalflowclustering_amd import KmeanGrids
+    from opticalflowclustering_amd.cluster import KMeans
+    from opticalflowclustering_amd.computeOpticalFlowModule import ComputeOpticalFLow
+    v = make_video(W=700, H=420, T=2)
+    src = str(tmp_path / "clip.npy")
+    np.save(src, v)
+    monkeypatch.chdir(tmp_path)
+    KmeanGrids.main(["-d", "OutImgs/clip", "-c", "3", "-f", "x.csv", "--noyolo", "--nocontour", "--path", src,
+                     "--init", "k-means++", "--seed", "2"])
+    rows = list(csv.reader(open(tmp_path / "OutCSV" / "clip.csv")))
+    got = [int(x) for x in rows[1]]
+    cf = ComputeOpticalFLow(v[0])
+    vis = cf.compute(v[1])
+    cf.close()
+    for c in range(0, 350, 11):
+        X = O.preprocess_rgba(O.extract_cell(vis, c)).reshape(-1, 4)
+        km = KMeans(n_clusters=3, init="k-means++", random_state=2).fit(X)
+        counts = np.bincount(km.predict(X), minlength=3)
+        dom = np.rint(km.cluster_centers_[int(np.argmax(counts))])
+        assert got[c] == int(O.bgr2hsv(dom[:3].astype(np.uint8).reshape(1, 1, 3))[0, 0, 0]), c
+
+
+def test_draw_grids_prerendered_variant(tmp_path, monkeypatch):
+    """drawGridsAndOutputCSV.py's own (older) form: a pre-rendered <name>_optical<ext> flow video, 10x10 grid, no cell
+    PNGs (drawGridsAndOutputCSV.py:147-148,168,173): per-frame hue rows of the grid means, and the overlay video"""
+    from opticalflowclustering_amd import drawGridsAndOutputCSV as D
+    v = make_video(W=640, H=400, T=4, seed=5)
+    flowvid = make_video(W=640, H=400, T=4, seed=9)
+    np.save(str(tmp_path / "clip.npy"), v)
+    np.save(str(tmp_path / "clip_optical.npy"), flowvid)
+    monkeypatch.chdir(tmp_path)
+    n = D.process_prerendered("clip", ".npy", csv_file="rgb.csv")
+    assert n == 3
+    rows = list(csv.reader(open(tmp_path / "rgb.csv")))
+    assert rows[0] == [f"cell_{i}" for i in range(100)] and len(rows) == 4
+    for t in (1, 2, 3):
+        # the reference reads the flow video in step with the source video AFTER consuming the source's first frame only
+        # (drawGridsAndOutputCSV.py:166,176-177): row t pairs source frame t with flow frame t-1
+        _, hsv = O.grid_cell_means(flowvid[t - 1], 10, 10)
+        assert [float(x) for x in rows[t]] == [float(h) for h in hsv[:, 0]]
+    data = open(tmp_path / "clip_output.mp4", "rb").read()
+    assert data[:4] == b"RIFF" and data.count(b"00dc") >= 3
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(cmd, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    p = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_distributed_path_end_to_end_on_one_gpu():
+    """bench.py's N > 1 code path in a fresh process under torch.distributed.run with a world-1 RCCL communicator
+    (OFC_FORCE_DIST=1): rendezvous over gloo, ofc_dist_init, the send != recv all-reduce of the Lloyd totals on the
+    library's stream, dist.finalize -- must give the centres and iteration count of the plain run"""
+    common = ["--gpus", "1", "--frames", "9", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extras"]
+    plain = _run_bench(["bench.py"] + common)
+    dist = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), "bench.py"] + common, {"OFC_FORCE_DIST": "1"})
+    for line in (plain, dist):
+        assert line["n_gpus"] == 1 and line["config"]["pairs"] == 8 and "roofline" in line
+    assert dist["config"]["lloyd_iters"] == plain["config"]["lloyd_iters"]
+    assert np.abs(np.array(dist["config"]["centers"]) - np.array(plain["config"]["centers"])).max() <= 1e-12
+    assert abs(dist["config"]["inertia"] - plain["config"]["inertia"]) <= 1e-10 * plain["config"]["inertia"]

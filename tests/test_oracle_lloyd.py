@@ -56,3 +56,22 @@ def test_kmeans_plusplus_host_logic_reproduces_sklearn_seeds(name):
     centers, idx = kmeans_plusplus(X, int(KPP[name + "/k"]), int(KPP[name + "/seed"]), _step=O.kpp_candidates)
     assert np.array_equal(idx, KPP[name + "/indices"])
     assert np.array_equal(centers, X[idx].astype(np.float64))
+
+
+KATKPP = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_kpp_goldens.npz"))
+
+
+def test_seeded_cluster_colors_on_reference_cells_matches_sklearn():
+    """k = 3 on cells of the reference's recorded visualisation, KMeans(n_clusters=3, random_state=0) as the reference
+    constructs it plus a seed (make_kat_kpp_goldens.py): k-means++ host logic + Lloyd oracle land on sklearn's centres"""
+    from opticalflowclustering_amd.cluster import kmeans_plusplus
+    kat = np.load(os.path.join(os.path.dirname(__file__), "golden", "kat_cells.npz"))
+    k, seed = int(KATKPP["k"]), int(KATKPP["seed"])
+    for j, c in enumerate(KATKPP["cell_index"]):
+        X = O.preprocess_rgba(kat["cells_rgb"][0][c]).reshape(-1, 4)
+        C0, _ = kmeans_plusplus(X, k, seed, _step=O.kpp_candidates)
+        cen, lab, _, n_iter = O.kmeans_fit(X, C0)
+        assert n_iter == int(KATKPP["n_iter"][j]), c
+        assert np.abs(cen - KATKPP["centers"][j]).max() <= 1e-9, c
+        counts = np.bincount(O.kmeans_predict(X, cen), minlength=k)
+        assert np.array_equal(np.rint(cen[int(np.argmax(counts))]), KATKPP["dominant_rint"][j]), c

@@ -1,0 +1,44 @@
+"""profiles/r02_pmc.json from the PMC passes of tools/roofline_pmc.sh: per kernel FETCH_SIZE / WRITE_SIZE means, the gfx950
+read correction (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B; checked here against
+TCC_EA0_RDREQ with no 32-B requests) and the fingerprint of the kernel source the passes belong to"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, ".")
+import bench
+
+out, tag = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = defaultdict(list)
+for path in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+W, H = 1920, 1080
+want = {"k_polyexp": ("k_polyexp<1, false>", 24 * W * H * 64, "64 x 1920x1080 images per launch"),
+        "k_flow_iter": ("k_flow_iter<7, 0>", 56 * W * H * 32, "32 x 1920x1080 pairs per launch, level-0 iteration 2/3")}
+rec = {"source_sha16": bench.source_sha16(), "tag": tag, "kernels": {},
+       "correction": "read bytes = 2 x FETCH_SIZE x 1024 (all read requests are 128 B: TCC_EA0_RDREQ_32B = 0 and "
+                     "FETCH_SIZE x 1024 = TCC_EA0_RDREQ x 64); WRITE_SIZE x 1024 exact",
+       "collected": "tools/roofline_pmc.sh: separate --pmc passes with --kernel-trace only, MI355X; summaries in "
+                    "profiles/%s_roofline_pmc_summary.txt, durations in profiles/%s_roofline_kernel_stats.csv" % (tag, tag)}
+for key, (pat, alg, cfg) in want.items():
+    name = [k for k in acc if pat in k]
+    assert len(name) == 1, (pat, list(acc))
+    c = {k: sum(v) / len(v) for k, v in acc[name[0]].items()}
+    assert c.get("TCC_EA0_RDREQ_32B_sum", 0) == 0
+    assert abs(c["FETCH_SIZE"] * 1024 - c["TCC_EA0_RDREQ_sum"] * 64) <= 0.02 * c["FETCH_SIZE"] * 1024, c
+    traffic = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
+    d = dur[name[0]]
+    rec["kernels"][key] = {"symbol": pat, "config": cfg, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+                           "read_bytes": 2 * c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
+                           "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg,
+                           "traffic_over_algorithmic": traffic / alg,
+                           "l2_hit_rate": c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1),
+                           "avg_launch_us_rocprof": sum(d) / max(len(d), 1)}
+json.dump(rec, open("profiles/r02_pmc.json", "w"), indent=1)
