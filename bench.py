@@ -43,10 +43,11 @@ MAX_BATCH = 32
 
 
 def auto_batch(n_pairs, max_batch=MAX_BATCH):
-    """equal batches of at most max_batch pairs: a 38-pair shard runs 19 + 19, never 32 + 6 (the tail batch's launches
-    cost almost what a full batch's cost)"""
+    """pairs per flow launch sequence.  A shard of a few batches is split evenly (38 pairs run 19 + 19 on the two
+    engines, never 32 + 6: measured 7.9 ms against 8.3 for one 38-pair batch); a long clip takes full 32-pair batches
+    and one short tail (299 pairs: 46.8 ms with 9 x 32 + 11 against 47.2 with 10 x 30)"""
     n_batches = -(-n_pairs // max_batch)
-    return -(-n_pairs // n_batches)
+    return max_batch if n_batches >= 4 else -(-n_pairs // n_batches)
 
 
 def main():
@@ -149,9 +150,9 @@ def main():
             out["config"]["labelled_fit_check"] = labelled_fit_check(pipe, centers, n_iter, device)
     pipe.close()
     if rank == 0 and world == 1 and not args.no_extras and args.frames == CLIP_FRAMES:
-        # (3) what one rank of an 8-GPU run does per step: its 38-pair shard of the same clip, alone on this GPU (no
-        # collective: RCCL refuses two ranks on one device) -- the number the >= 6x scaling target is priced on
-        out["config"]["shard_step_ms"] = shard_step_ms(device, args.engines)
+        # (3) what one rank of an 8-GPU run does per step, alone on this GPU (no collective: RCCL refuses two ranks on one
+        # device) -- the numbers the >= 6x scaling target is priced on
+        out["config"].update(shard_step_ms(device, args.engines, centers, int(n_iter)))
     if rank == 0:
         # ---- roofline leg: the polyexp kernel, HIP events on its own stream, 64 distinct 1080p images ----
         n_img, iters = 64, 20
@@ -199,26 +200,35 @@ def labelled_fit_check(pipe, centers, n_iter, device):
     return {"ok": bool(ok), "n_iter": [int(n_iter), int(it2)], "max_abs_centre_diff": float(np.abs(c2 - centers).max())}
 
 
-def shard_step_ms(device, engines, steps=10):
-    """one rank's share of configs[3]: pairs [0, 38) of the clip, flow + Lloyd to convergence over its own vectors"""
+def shard_step_ms(device, engines, global_centers, global_iters, steps=10):
+    """rank 0's share of configs[3]: pairs [0, 38) of the clip.
+    shard_step_ms       flow + a self-contained Lloyd fit over the shard's own vectors (its own iteration count; on this
+                        clip the shard alone meets an empty cluster and takes the labelled path)
+    shard_rank_step_ms  flow + exactly the device work the rank does inside the 8-GPU fit: the clip-wide fit's number of
+                        label-less sweeps over its 38 pairs (started from the converged clip-wide centres, with a negative tol so
+                        that exactly max_iter = that many run), column statistics and the final E-step: everything but the collectives"""
     from opticalflowclustering_amd import _lib
     from opticalflowclustering_amd.pipeline import ClipPipeline, shard_pairs
     p0, p1 = shard_pairs(CLIP_FRAMES - 1, 8, 0)
     pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=auto_batch(p1 - p0), device=device, n_engines=engines)
     pipe.synth(t0=p0, seed=0)
     lib = _lib.load()
-    for _ in range(2):
-        pipe.run_flow(sync=False)
-        pipe.run_kmeans(INIT, max_iter=300, tol=1e-4)
-    _lib.check(lib.ofc_device_sync(device))
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.run_flow(sync=False)
-        pipe.run_kmeans(INIT, max_iter=300, tol=1e-4)
-    _lib.check(lib.ofc_device_sync(device))
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    res = {}
+    for key, init, kw in (("shard_step_ms", INIT, dict(max_iter=300, tol=1e-4)),
+                          ("shard_rank_step_ms", np.asarray(global_centers), dict(max_iter=global_iters, tol=-1.0))):
+        for _ in range(2):
+            pipe.run_flow(sync=False)
+            r = pipe.run_kmeans(init, **kw)
+        _lib.check(lib.ofc_device_sync(device))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.run_flow(sync=False)
+            r = pipe.run_kmeans(init, **kw)
+        _lib.check(lib.ofc_device_sync(device))
+        res[key] = (time.perf_counter() - t0) / steps * 1e3
+        res[key.replace("_ms", "_lloyd_iters")] = int(r[2])
     pipe.close()
-    return ms
+    return res
 
 
 def source_sha16():
@@ -287,14 +297,17 @@ def cpu_baseline(device, single_pairs=4, multi_pairs=32):
     try:
         import warnings
         from sklearn.cluster import KMeans
+        Xs = X[: 8 * P]
         t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            km = KMeans(n_clusters=K_CLUSTERS, init=INIT, n_init=1, max_iter=300, tol=1e-4).fit(X)
+            km = KMeans(n_clusters=K_CLUSTERS, init=INIT, n_init=1, max_iter=300, tol=1e-4).fit(Xs)
         t_sk = time.perf_counter() - t0
         import sklearn
-        sk = {"value": len(X) / 1e6 / t_sk, "unit": "Mpoints/s (Lloyd only)", "seconds": t_sk, "n_iter": int(km.n_iter_),
-              "version": sklearn.__version__, "sample": "the %d (u,v) vectors of (b), f32 as the flow produces them" % len(X)}
+        sk = {"value": len(Xs) * km.n_iter_ / 1e6 / t_sk, "unit": "Mpoint-iterations/s (Lloyd only, all cores)",
+              "seconds": t_sk, "n_iter": int(km.n_iter_), "version": sklearn.__version__,
+              "sample": "the %d (u,v) vectors of the first 8 pairs, f32 as the flow produces them; for comparison the "
+                        "oracle's all-core Lloyd above runs %.0f Mpoint-iterations/s" % (len(Xs), len(X) * it / 1e6 / t_km)}
     except Exception as e:                              # not importable on this box
         sk = "unavailable on this box (%s)" % e.__class__.__name__
     return {"value": allc["value"], "unit": "Mpixels/s", "cores": cores, "kind": "port",
@@ -342,12 +355,15 @@ def bench_cfg4(args, device):
     from opticalflowclustering_amd.stream import FlowStream
     W4, H4, n = 3840, 2160, args.frames4k
     p = synth.texture_params(0)
-    base = [synth.frame(W4, H4, 0.9 * t, -0.5 * t, p).astype(np.uint8) for t in range(8)]
+    # eight vertical bands moving with eight different velocities (so that k = 8 has something to find); the stream walks
+    # the eight distinct frames back and forth (0..7,6..1,0..): every consecutive pair is one motion step
+    base = [synth.frame(W4, H4, *synth.population_motion(W4, H4, t, n_pop=8, seed=4)[:2], p).astype(np.uint8) for t in range(8)]
+    order = list(range(8)) + list(range(6, 0, -1))
     fs = FlowStream(W4, H4, batch_pairs=8, device=device)
 
     def step():
         for t in range(n):
-            fs.push(base[t % 8])
+            fs.push(base[order[t % len(order)]])
         cells = fs.finish()
         km = KMeans(n_clusters=8, init="seeded-rows", random_state=0, device=device).fit(cells.reshape(-1, 2))
         return cells, km

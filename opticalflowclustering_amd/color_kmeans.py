@@ -65,7 +65,7 @@ def dominant_cluster(image_rgba, n_clusters, device=0, init="seeded-rows", rando
     label_percentages = label_counts.astype(float) / len(flattened_image)  # :88
     label_info = [(label_percentages[i], f"Cluster {i + 1}", centroid) for i, centroid in enumerate(clt.cluster_centers_)]
     label_info = sorted(label_info, key=lambda x: x[0], reverse=True)      # :96 (stable)
-    cluster0 = np.rint(label_info[0][2])                                   # :112
+    cluster0 = np.rint(label_info[0][2]) + 0.0                             # :112 (+0.0: a centre of -1e-16 prints "0.", not "-0.")
     r0, g0, b0, a0 = cluster0
     hsv0 = bgr2hsv_pixel([r0, g0, b0], device)                             # :117-121 (BGR2HSV on whatever order came in)
     return cluster0, hsv0, clt

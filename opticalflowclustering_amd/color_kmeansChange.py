@@ -43,7 +43,7 @@ def process_folder(folder, n_clusters, device=0, init="maximin", seed=0):
     out = []
     for p, n in enumerate(names):
         dom = int(np.argmax(counts[p]))                     # stable: first maximum, as sorted(..., reverse=True)
-        c0 = np.rint(centers[p, dom])
+        c0 = np.rint(centers[p, dom]) + 0.0
         out.append((n, c0, bgr2hsv_pixel(c0[:3], device)))
     return out
 

@@ -59,7 +59,7 @@ def run(images_dir, csv_file, n_clusters=1, device=0, init="seeded-rows", seed=0
                                                    device=device)
         for i, (n, _) in enumerate(small):
             dom = int(np.argmax(counts[i]))                    # stable: first maximum, as sorted(..., reverse=True)
-            c0 = np.rint(centers[i, dom])
+            c0 = np.rint(centers[i, dom]) + 0.0
             results[n] = (c0, bgr2hsv_pixel(c0[:3], device))
     with open(csv_file, "a", newline="") as f:
         w = csv.writer(f)

@@ -360,7 +360,9 @@ struct PolyArgs {
 // fly from the frame instead of being read back as an f32 image: 1 B/px read instead of 4, and the level-0 image
 // kernel with its 5 B/px disappears.  Every intermediate value of that blur is a multiple of 1/16 below 256, exactly
 // representable in f32 whatever the evaluation order, so the result is bit-identical to k_level0 + this kernel.
-template <int TAG, bool U8IN>
+// F64H: the six horizontal sums exactly as the reference forms them (double accumulators; b1/b4 from double products, the
+// other four from float products) -- a study / fallback build (OFC_POLYEXP_F64=1): see DESIGN.md section 2.
+template <int TAG, bool U8IN, bool F64H = false>
 __global__ __launch_bounds__(256, 3) void k_polyexp(const void *__restrict__ Iv, float *__restrict__ R,
                                                  PolyArgs p)
 {
@@ -481,6 +483,29 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const void *__restrict__ Iv,
                     // the same as with f64 accumulators, for 40 % less time in this VALU-bound pass.
                     // packed over PAIRS OF SUMS (not pairs of pixels, whose operands would straddle register pairs):
                     // per tap pair 3 packed adds + 3 packed fmas instead of 5 + 6 scalar ones
+                    float b1, b2, b3, b4, b5, b6;
+                    double d1 = 0, d4 = 0, d5 = 0;
+                    if (F64H) {
+#pragma clang fp contract(off)
+                        double e1 = (double)(A[c].x * p.g[0]), e2 = 0, e3 = (double)(A[c].y * p.g[0]), e4 = 0,
+                               e5 = (double)(Q[c].x * p.g[0]), e6 = 0;
+#pragma unroll
+                        for (int k = 1; k <= PE_N; k++) {
+                            const double tg = (double)(A[c + k].x + A[c - k].x);
+                            e1 += tg * (double)p.g[k];
+                            e4 += tg * (double)p.xxg[k];
+                            e2 += (double)((A[c + k].x - A[c - k].x) * p.xg[k]);
+                            e3 += (double)((A[c + k].y + A[c - k].y) * p.g[k]);
+                            e6 += (double)((A[c + k].y - A[c - k].y) * p.xg[k]);
+                            e5 += (double)((Q[c + k].x + Q[c - k].x) * p.g[k]);
+                        }
+                        d1 = e1; d4 = e4; d5 = e5;
+                        b1 = (float)e1; b4 = (float)e4; b5 = (float)e5;
+                        r1[o] = (float)(e2 * p.ig11);
+                        r0[o] = (float)(e3 * p.ig11);
+                        r4[o] = (float)(e6 * p.ig55);
+                        b2 = b3 = b6 = 0.f;
+                    } else {
                     v2f b14 = {A[c].x * p.g[0], 0.f};                    // (b1, b4)
                     v2f b26 = {0.f, 0.f};                                // (b2, b6)
                     v2f b53 = Q[c] * (v2f){p.g[0], p.g[0]};              // (b5, b3)
@@ -493,12 +518,19 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const void *__restrict__ Iv,
                         b26 = __builtin_elementwise_fma(df, (v2f){p.xg[k], p.xg[k]}, b26);
                         b53 = __builtin_elementwise_fma(sq, (v2f){p.g[k], p.g[k]}, b53);
                     }
-                    const float b1 = b14.x, b4 = b14.y, b2 = b26.x, b6 = b26.y, b5 = b53.x, b3 = b53.y;
-                    r1[o] = b2 * (float)p.ig11;
-                    r0[o] = b3 * (float)p.ig11;
-                    r3[o] = (float)((double)b1 * p.ig03 + (double)b4 * p.ig33);
-                    r2[o] = (float)((double)b1 * p.ig03 + (double)b5 * p.ig33);
-                    r4[o] = b6 * (float)p.ig55;
+                    b1 = b14.x; b4 = b14.y; b2 = b26.x; b6 = b26.y; b5 = b53.x; b3 = b53.y;
+                    }
+                    if (F64H) {
+#pragma clang fp contract(off)
+                        r3[o] = (float)(d1 * p.ig03 + d4 * p.ig33);
+                        r2[o] = (float)(d1 * p.ig03 + d5 * p.ig33);
+                    } else {
+                        r1[o] = b2 * (float)p.ig11;
+                        r0[o] = b3 * (float)p.ig11;
+                        r3[o] = (float)((double)b1 * p.ig03 + (double)b4 * p.ig33);
+                        r2[o] = (float)((double)b1 * p.ig03 + (double)b5 * p.ig33);
+                        r4[o] = b6 * (float)p.ig55;
+                    }
                 }
                 // R is pixel-interleaved ([y][x][5], as OpenCV keeps it) so that the consumer's bilinear taps are two
                 // 40-byte runs instead of 20 scattered dwords.  A lane's 4 px x 5 coefficients are 80 contiguous bytes;
@@ -559,6 +591,13 @@ __global__ __launch_bounds__(256, 3) void k_polyexp(const void *__restrict__ Iv,
 }
 
 
+// OFC_POLYEXP_F64=1: horizontal sums in double, as the reference (read at every launch: a test toggles it)
+static bool polyexp_f64()
+{
+    const char *e = getenv("OFC_POLYEXP_F64");
+    return e && e[0] == '1';
+}
+
 int polyexp_default_rows(int W, int H, int nimg)
 {
     // 16-row strips: the 10-row window warm-up re-reads input rows that the strip above is reading at about the same
@@ -594,7 +633,8 @@ int launch_polyexp_u8(const uint8_t *frames, float *R, int nimg, int W, int H, c
     PolyArgs a;
     polyexp_args(a, W, H, nimg, c, 0);
     dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
-    hipLaunchKernelGGL((k_polyexp<0, true>), grid, dim3(256), 0, s, frames, R, a);
+    if (polyexp_f64()) hipLaunchKernelGGL((k_polyexp<0, true, true>), grid, dim3(256), 0, s, frames, R, a);
+    else hipLaunchKernelGGL((k_polyexp<0, true>), grid, dim3(256), 0, s, frames, R, a);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }
@@ -605,7 +645,8 @@ int launch_polyexp(const float *I, float *R, int nimg, int W, int H, const PolyC
     PolyArgs a;
     polyexp_args(a, W, H, nimg, c, rows_per_block);
     dim3 grid(cdiv(W, PE_TX), cdiv(H, a.rows_per_block), nimg);
-    if (bench_tag) hipLaunchKernelGGL((k_polyexp<1, false>), grid, dim3(256), 0, s, I, R, a);
+    if (polyexp_f64()) hipLaunchKernelGGL((k_polyexp<2, false, true>), grid, dim3(256), 0, s, I, R, a);
+    else if (bench_tag) hipLaunchKernelGGL((k_polyexp<1, false>), grid, dim3(256), 0, s, I, R, a);
     else hipLaunchKernelGGL((k_polyexp<0, false>), grid, dim3(256), 0, s, I, R, a);
     OFC_HIP(hipGetLastError());
     return OFC_OK;

@@ -199,15 +199,18 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     // previous iteration had the same empty cluster.
     //
     // The convergence test runs on the device (k_lloyd_update) and the host enqueues LLOYD_WINDOW iterations per
-    // synchronisation: an iteration behind the one that converged (or met an empty cluster) finds st->halt set and
-    // does nothing.  One host round trip per window instead of one per iteration (18 us each -- a tenth of an
+    // synchronisation (windows of 4, 8, 16, 16, ...): an iteration behind the one that converged (or met an empty cluster)
+    // finds st->halt set and does nothing.  One host round trip per window instead of one per iteration (18 us each -- a tenth of an
     // iteration on a 1/8 shard); every rank takes the same decisions because they derive from all-reduced totals.
     bool strict = false, labelled = false, stop = false;
     int it = 0;
     const int *halt = &st->halt;
     double *tot_local = dist_has_comm() ? sc.tot_local.as<double>() : tot;
+    int window = 4;                       // 4, 8, 16, 16, ...: an 11-iteration fit costs two host round trips, and a fit
+                                          // that meets its empty cluster early (iteration 1-2, typically) wastes few
     while (it < max_iter && !stop) {
-        const int nwin = std::min(LLOYD_WINDOW, max_iter - it);
+        const int nwin = std::min(window, max_iter - it);
+        window = std::min(2 * window, LLOYD_WINDOW);
         for (int w = 0; w < nwin; w++) sc.status[w].valid = 0;
         for (int w = 0; w < nwin; w++) {
             OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,

@@ -47,7 +47,7 @@ inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + 1 + LLOY
 // column sums of (x-mean)^2 in tot, n_total samples and tol_rel
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
                         double n_total, double tol_rel, LloydStatus *status, hipStream_t s);
-constexpr int LLOYD_WINDOW = 4;     // iterations enqueued per host synchronisation
+constexpr int LLOYD_WINDOW = 16;    // most iterations enqueued per host synchronisation (windows grow 4, 8, 16, 16, ...)
 int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s);
 int launch_lloyd_inertia(const void *X, int dtype, int64_t N, int d, const LloydState *st,
                          const uint8_t *labels, double *partial, int nblocks, hipStream_t s);

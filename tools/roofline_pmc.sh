@@ -9,7 +9,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" 
   t=$(echo $pass | tr ' ' '_' | cut -c1-32)
   timeout -k 10 180 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/$t -- python3 tools/roofline_pmc.py > $out/$t.log 2>&1 || { echo "pass $t failed"; tail -5 $out/$t.log; exit 1; }
 done
-timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/roofline_pmc.py > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
+timeout -k 10 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/roofline_pmc.py 20 10 > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
 python3 tools/pmc_summary.py $out > profiles/${tag}_roofline_pmc_summary.txt
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) profiles/${tag}_roofline_kernel_stats.csv
 python3 tools/make_pmc_json.py $out $tag
