@@ -118,8 +118,18 @@ def test_cli_parsers_match_reference_flags():
     from opticalflowclustering_amd import KmeanGrids, color_kmeans, color_kmeansChange
     a = KmeanGrids.parse_arguments(["-d", "OutImgs/v", "-c", "1", "-f", "x.csv", "--noyolo", "--nocontour", "--path", "v.mp4"])
     assert a["dir"] == "OutImgs/v" and a["clusters"] == 1 and a["noyolo"] is False and a["nocontour"] is False
-    assert color_kmeans.parse_arguments(["-i", "a.png", "-c", "3", "-f", "o.csv"]) == {"image": "a.png", "clusters": 3, "csv": "o.csv"}
-    assert color_kmeansChange.parse_arguments(["-d", "D", "-c", "1", "-f", "o.csv"])["dir"] == "D"
+    # the reference's flags, plus the seeding / device extension (SURVEY.md section 5 "config / flags") with defaults that
+    # leave the documented commands unchanged
+    assert color_kmeans.parse_arguments(["-i", "a.png", "-c", "3", "-f", "o.csv"]) == {
+        "image": "a.png", "clusters": 3, "csv": "o.csv", "init": "seeded-rows", "seed": 0, "device": 0}
+    assert color_kmeansChange.parse_arguments(["-d", "D", "-c", "1", "-f", "o.csv"]) == {
+        "dir": "D", "clusters": 1, "csv": "o.csv", "init": "maximin", "seed": 0, "device": 0}
+    assert a["init"] == "maximin" and a["seed"] == 0 and a["device"] == 0
+    b = KmeanGrids.parse_arguments(["-d", "OutImgs/v", "-c", "3", "-f", "x.csv", "--path", "v.mp4", "--init", "k-means++",
+                                    "--seed", "7", "--device", "1"])
+    assert (b["init"], b["seed"], b["device"], b["noyolo"]) == ("k-means++", 7, 1, True)
+    with pytest.raises(SystemExit):
+        KmeanGrids.parse_arguments(["-d", "x", "-c", "1", "-f", "x.csv", "--path", "v", "--init", "random"])
     with pytest.raises(SystemExit):
         color_kmeans.parse_arguments(["-i", "a.png"])
 
