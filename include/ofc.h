@@ -124,12 +124,14 @@ int ofc_flow_resize(int device, const float *flow, int sw, int sh, int dw, int d
 
 /* `iters` Farneback iterations (update matrices + box mean + solve, as ofc_update_matrices / ofc_box_solve chained:
  * oracle/farneback_ref.c, the loop of FarnebackUpdateFlow_Blur) from flow_in, with the engine's fused kernels.
- * mode 0: one launch per iteration; mode 1: two iterations per launch where possible (the engine's default at the
- * wide pyramid levels); rows_per_block 0 = automatic strip height.  Parity-test hook. */
+ * mode 0: one launch per iteration (k_flow_iter); mode 1: two iterations per launch where possible (k_flow_iter2);
+ * mode 2: one launch per iteration with the 3-waves-per-SIMD kernel (k_flow_iter_w3); rows_per_block 0 = automatic
+ * strip height.  Parity-test hook. */
 int ofc_flow_iterate(int device, const float *R0, const float *R1, const float *flow_in, int W, int H,
                      int winsize, int iters, int mode, int rows_per_block, float *flow_out);
 /* bench hook: one 1080p-style level of `n_pairs` resident pairs, the last two of the three iterations of a level
- * timed with HIP events on their stream: mode 0 = two single-iteration launches, mode 1 = one two-iteration launch.
+ * timed with HIP events on their stream: mode 0 = two single-iteration launches, mode 1 = one two-iteration launch,
+ * mode 2 = two launches of the 3-waves-per-SIMD kernel.
  * *ms = average duration of those two iterations per batch. */
 int ofc_bench_flow_iters(int device, int W, int H, int n_pairs, int reps, int mode, float *ms);
 

@@ -1469,6 +1469,181 @@ __global__ __launch_bounds__(2 * C, 2) void k_flow_iter2(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K4+K5 fused, THREE work-groups per CU.  k_flow_iter keeps 244 VGPRs (80 of them the ring of M rows, 112 the gathered
+// operands of four rows in flight) and therefore runs at 2 waves per SIMD; its counters say a wave issues instructions 39 %
+// of its life, waits on memory / barriers 24 % and stalls on dependent (mostly f64) instructions 37 %, with 1.6 waves per SIMD
+// on average: the SIMDs idle for lack of waves.  This form fits 168 VGPRs = 3 waves per SIMD:
+//   * two rows per step (56 operand registers instead of 112),
+//   * the ring split: 10 of its 16 row slots in registers, 6 in LDS ([slot][channel][column] floats: conflict-free
+//     lane <-> column accesses, 30 KB), every slot index a compile-time constant after unrolling 8 steps,
+//   * the horizontal pass on 2 outputs per lane (all four waves busy on the step's two rows).
+// LDS 52.5 KB per work-group -> 3 per CU (157 KB).  Same arithmetic as k_flow_iter per pixel; the horizontal f64 sums
+// group differently (2 outputs per lane), as in k_flow_iter2.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256, 3) void k_flow_iter_w3(const float *__restrict__ Rb, size_t frame_stride_R,
+                                                         const float *__restrict__ flow_inb,
+                                                         float *__restrict__ flow_outb, int W, int H,
+                                                         int rows_per_block /* even */, int tiles_x, int n_strips,
+                                                         int npair)
+{
+    constexpr int C = 256, TXO = C - 2 * M, VP = C + 16, RREG = 10, RLDS = 16 - RREG;
+    __shared__ __align__(16) double vs[5][2][VP];
+    __shared__ float lring[RLDS][5][C];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = tiles_x * n_strips;
+    const int group = blockIdx.x / (8 * npair), rem = blockIdx.x - group * (8 * npair);
+    const int pair = rem >> 3, tile = group * 8 + (rem & 7);
+    if (tile >= tiles) return;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * TXO;
+    const int y_begin = tile_y * rows_per_block;
+    const int y_end = min(y_begin + rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *R0 = Rb + (size_t)pair * frame_stride_R;
+    const float *R1 = R0 + frame_stride_R;
+    const float2 *flow_in = reinterpret_cast<const float2 *>(flow_inb) + (size_t)pair * plane;
+    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)pair * plane;
+    const int xc = min(max(x0 - M + tid, 0), W - 1);
+    const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+    const int nst = 8 + (y_end - y_begin + 1) / 2;       // local step j ingests rows y_begin - 8 + 2j + {0,1}; emits from j = 8
+
+    float ring[RREG][5];
+    double v[5] = {0, 0, 0, 0, 0};
+    float2 fln[2];
+    auto row_of = [&](int j, int r) -> int { return min(max(y_begin - 8 + 2 * j + r, 0), H - 1); };
+#pragma unroll
+    for (int r = 0; r < 2; r++) fln[r] = flow_in[(size_t)row_of(0, r) * W + xc];
+
+    for (int j0 = 0; j0 < nst; j0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int j = j0 + q;
+            if (j < nst) {                                     // uniform
+                float mi[2][5];
+                {
+                    UmIn u[2];
+                    float2 fl[2];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) fl[r] = fln[r];
+                    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) um_load(R0, R1, plane, W, H, xc, row_of(j, r), fl[r], u[r]);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) fln[r] = flow_in[(size_t)row_of(j + 1, r) * W + xc];
+                    __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) um_math(u[r], W, H, xc, row_of(j, r), fl[r], mi[r]);
+                }
+                __syncthreads();                               // the previous step's horizontal pass is done with vs
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int s_in = (2 * q + r) & 15, s_out = (2 * q + r + 1) & 15;
+                    if (j >= 8) {
+                        float mo[5];
+                        if (s_out < RREG) {
+#pragma unroll
+                            for (int ch = 0; ch < 5; ch++) mo[ch] = ring[s_out < RREG ? s_out : 0][ch];
+                        } else {
+#pragma unroll
+                            for (int ch = 0; ch < 5; ch++) mo[ch] = lring[s_out >= RREG ? s_out - RREG : 0][ch][tid];
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) {
+                            vs[ch][r][tid] = v[ch];
+                            v[ch] += (double)mi[r][ch] - (double)mo[ch];
+                        }
+                    } else if (j > 0 || r > 0) {               // warm-up; the very first row lies outside the first window
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) v[ch] += (double)mi[r][ch];
+                    }
+                    if (s_in < RREG) {
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) ring[s_in < RREG ? s_in : 0][ch] = mi[r][ch];
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) lring[s_in >= RREG ? s_in - RREG : 0][ch][tid] = mi[r][ch];
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_s_setprio(0);
+                if (j >= 8) {
+                    const int item = 128 * wl + 2 * lane;
+                    const int r = item / C, t = item - r * C;          // outputs t, t+1 <-> image columns x0 + t, x0 + t + 1
+                    const int y = y_begin + 2 * (j - 8) + r;
+                    if (y < y_end && t < TXO && x0 + t < W) {
+                        double S[5][2];
+#pragma unroll
+                        for (int ch = 0; ch < 5; ch++) {
+                            const double *base = &vs[ch][r][t];
+                            double a[16];
+#pragma unroll
+                            for (int k = 0; k < 8; k++) {
+                                const double2 d = *reinterpret_cast<const double2 *>(base + 2 * k);
+                                a[2 * k] = d.x; a[2 * k + 1] = d.y;
+                            }
+                            double s = a[0];
+#pragma unroll
+                            for (int k = 1; k <= 2 * M; k++) s += a[k];
+                            S[ch][0] = s;
+                            s += a[2 * M + 1] - a[0];
+                            S[ch][1] = s;
+                        }
+                        float2 fo[2];
+#pragma unroll
+                        for (int o = 0; o < 2; o++) {
+                            const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                         h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                            fo[o] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                        }
+                        float2 *dst = flow_out + (size_t)y * W + x0 + t;
+                        if (t + 1 < TXO && x0 + t + 1 < W && (W & 1) == 0) {     // 16 contiguous, 16-B aligned bytes (x0, t even)
+                            *reinterpret_cast<float4 *>(dst) = make_float4(fo[0].x, fo[0].y, fo[1].x, fo[1].y);
+                        } else {
+                            dst[0] = fo[0];
+                            if (t + 1 < TXO && x0 + t + 1 < W) dst[1] = fo[1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int flow_iter_w3_rows(int W, int H, int npair, int winsize)
+{
+    const int tiles_x = cdiv(W, 256 - (winsize - 1));
+    const int resident = 3 * 256;
+    int best_rows = cdiv(H, 2) * 2;
+    int64_t best_cost = LLONG_MAX;
+    for (int n = 1; n <= 64; n++) {
+        const int rows = cdiv(cdiv(H, n), 2) * 2;
+        if (rows < 16 && n > 1) break;
+        const int64_t blocks = (int64_t)tiles_x * cdiv(H, rows) * npair;
+        const int64_t cost = cdiv64(blocks, resident) * (rows + 16);
+        if (cost < best_cost) { best_cost = cost; best_rows = rows; }
+    }
+    return best_rows;
+}
+
+int launch_flow_iter_w3(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                        int H, int winsize, hipStream_t s, int rows_per_block)
+{
+    if (winsize != 15) { set_error("k_flow_iter_w3 is built for winsize 15 only (got %d)", winsize); return OFC_EUNSUPPORTED; }
+    if ((int64_t)W * H * 5 >= (1ll << 30)) { set_error("frame too large for 32-bit R offsets (%dx%d)", W, H); return OFC_EUNSUPPORTED; }
+    if (rows_per_block <= 0) rows_per_block = flow_iter_w3_rows(W, H, npair, winsize);
+    rows_per_block = cdiv(rows_per_block, 2) * 2;
+    const int tx = cdiv(W, 256 - 14), ns = cdiv(H, rows_per_block);
+    dim3 grid(cdiv(tx * ns, 8) * 8 * npair);
+    hipLaunchKernelGGL((k_flow_iter_w3<7>), grid, dim3(256), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                       rows_per_block, tx, ns, npair);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
 // strip height of the two-iteration kernel: rounds x (steps per strip), one work-group per CU
 int flow_iter2_rows(int W, int H, int npair, int winsize, int C)
 {

@@ -227,6 +227,8 @@ struct ofc_flow {
     bool fuse2 = false;             // iterations 2+3 of a level in one launch (k_flow_iter2): measured SLOWER than two launches
                                     // on MI355X, kept as an opt-in experiment: OFC_FLOW_FUSE2=1 ...
     int fuse2_min_w = 0;            // ... or OFC_FLOW_FUSE2=<N > 1>: only at pyramid levels at least N pixels wide
+    bool w3 = false;                // iterations 2.. of a level with the 3-waves-per-SIMD kernel (k_flow_iter_w3): OFC_FLOW_W3
+    int w3_min_w = 0;
     DevBuf frames2, flow1;          // staging for the host-pointer entry points (batch of 1)
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
@@ -283,6 +285,8 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
                         cur = z;
                     }
                     if (plan[l] == 2) OFC_TRY(launch_flow_iter2(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
+                    else if (f->w3 && f->prm.winsize == 15 && g.w >= f->w3_min_w)
+                        OFC_TRY(launch_flow_iter_w3(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
                     else OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
                 }
                 cur = nxt;
@@ -335,6 +339,12 @@ int ofc_flow_create(int device, int W, int H, const ofc_fb_params *p, int max_ba
         const char *e = getenv("OFC_FLOW_STAGED");      // debugging aid: force the separate K4 / K5 kernels
         f->fused = prm.winsize <= 15 && !(e && e[0] == '1');
         f->fuse_level0 = !(e && e[0] == '1');            // the staged mode also keeps the separate level-0 image
+        const char *e3 = getenv("OFC_FLOW_W3");           // 1: everywhere; N > 1: at levels >= N wide; 0: off
+        if (e3 && e3[0]) {
+            const int v = atoi(e3);
+            f->w3 = v != 0;
+            f->w3_min_w = v > 1 ? v : 0;
+        }
         const char *e2 = getenv("OFC_FLOW_FUSE2");       // 1: two iterations per launch; N > 1: at levels >= N wide
         if (e2 && e2[0]) {
             const int v = atoi(e2);
@@ -612,6 +622,7 @@ int ofc_flow_iterate(int device, const float *R0, const float *R1, const float *
     for (int i = 0; i < iters;) {
         const int n = (mode == 1 && iters - i >= 2) ? 2 : 1;
         if (n == 2) OFC_TRY(launch_flow_iter2(dR.as<float>(), 5 * P, cur, nxt, 1, W, H, winsize, nullptr, rows_per_block));
+        else if (mode == 2) OFC_TRY(launch_flow_iter_w3(dR.as<float>(), 5 * P, cur, nxt, 1, W, H, winsize, nullptr, rows_per_block));
         else OFC_TRY(launch_flow_iter(dR.as<float>(), 5 * P, cur, nxt, 1, W, H, winsize, nullptr));
         std::swap(cur, nxt);
         i += n;
@@ -646,6 +657,10 @@ int ofc_bench_flow_iters(int device, int W, int H, int n_pairs, int reps, int mo
     OFC_HIP(hipEventCreate(&e1));
     auto two = [&]() -> int {
         if (mode == 1) return launch_flow_iter2(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s);
+        if (mode == 2) {
+            OFC_TRY(launch_flow_iter_w3(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s));
+            return launch_flow_iter_w3(R.as<float>(), 5 * P, fb.as<float>(), fa.as<float>(), n_pairs, W, H, 15, s);
+        }
         OFC_TRY(launch_flow_iter(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s));
         // second iteration in place of the pair's scratch: fb -> fa would overwrite the input; write a third pass back to fb
         return launch_flow_iter(R.as<float>(), 5 * P, fb.as<float>(), fa.as<float>(), n_pairs, W, H, 15, s);

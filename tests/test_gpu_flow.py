@@ -379,3 +379,17 @@ def test_polyexp_f64_horizontal_variant(st, monkeypatch):
     slow = st.polyexp(img)
     e_fast, e_slow = np.abs(fast - want).max(), np.abs(slow - want).max()
     assert e_fast <= 2e-5 * np.abs(want).max() and e_slow <= e_fast
+
+
+@pytest.mark.parametrize("W,H,rows", [(480, 270, 0), (700, 96, 0), (243, 40, 0), (242, 18, 0), (1000, 300, 64),
+                                      (457, 131, 16), (64, 16, 0), (300, 17, 0), (963, 541, 0)])
+def test_three_wave_iteration_kernel_equals_the_two_wave_one(st, W, H, rows):
+    """k_flow_iter_w3 (ring split between registers and LDS, two rows per step, 3 waves per SIMD): same arithmetic per pixel
+    as k_flow_iter; the f64 horizontal sums group differently (2 outputs per lane instead of 4)"""
+    R0, R1, flow = _iter_case(W, H, seed=W + 1)
+    one = st.flow_iterate(R0, R1, flow, 3, mode=0)
+    w3 = st.flow_iterate(R0, R1, flow, 3, mode=2, rows_per_block=rows)
+    assert np.isfinite(w3).all()
+    d = np.abs(one - w3)
+    assert d.max() <= 1e-6 * max(1.0, np.abs(one).max()), d.max()
+    assert (d == 0).mean() >= 0.999
