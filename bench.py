@@ -185,6 +185,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(device)
     if world > 1 or force_dist:
+        barrier()            # rank 0 ran the roofline legs meanwhile: tear the communicator down together
         dist.finalize()
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -13,3 +13,4 @@ timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/
 cat gpurun_out/bench_default.json
 timeout -k 10 300 python bench.py --workload cfg4 --steps 2 > gpurun_out/bench_cfg4.json 2> gpurun_out/bench_cfg4.err || tail -5 gpurun_out/bench_cfg4.err
 cat gpurun_out/bench_cfg4.json
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
