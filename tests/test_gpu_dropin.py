@@ -504,3 +504,40 @@ def test_streaming_ingest_at_4k_against_oracle():
     # interior cells recover the true motion (1.3, -0.7) px/frame
     inner = cells.reshape(T - 1, 14, 25, 2)[:, 2:-2, 2:-2]
     assert np.abs(inner[..., 0] - 1.3).max() < 0.05 and np.abs(inner[..., 1] + 0.7).max() < 0.05
+
+
+def test_full_size_clip_properties():
+    """BASELINE.json configs[2] at its full size (300 x 1080p, 6.2e8 (u,v) vectors) through size-independent properties:
+    batch independence of the flow (pairs computed 32 at a time equal pairs computed 19 at a time, bit for bit), Lloyd
+    restart (a fit started from the tol-converged centres stops within two iterations, moves them by less than the
+    tolerance scale and does not increase the inertia), and agreement of the
+    label-less in-library fit with the labelled host-driven one (centres, iteration count, inertia)."""
+    from opticalflowclustering_amd import _lib
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    from opticalflowclustering_amd.sharded import DeviceShard, fit_sharded
+    W, H, T = 1920, 1080, 300
+    init = np.array([[-3.0, -3.0], [-1.5, 1.0], [0.0, 0.0], [1.5, -1.0], [3.0, 3.0]])
+    pipe = ClipPipeline(W, H, T, batch_pairs=32, n_engines=2)
+    pipe.synth(t0=0, seed=0)
+    pipe.run_flow()
+    P = W * H
+    head = pipe.flows.download((19, H, W, 2), np.float32)
+    tail = pipe.flows.download((1, H, W, 2), np.float32, offset=298 * P * 8)
+    assert np.isfinite(head).all() and np.isfinite(tail).all() and np.abs(tail).max() > 0.1
+    small = ClipPipeline(W, H, 20, batch_pairs=19, n_engines=1)
+    small.synth(t0=0, seed=0)
+    small.run_flow()
+    assert np.array_equal(small.flows.download((19, H, W, 2), np.float32), head)
+    small.close()
+    del head, tail
+    centers, inertia, n_iter = pipe.run_kmeans(init)
+    assert 2 <= n_iter <= 300
+    c2, inertia2, n2 = pipe.run_kmeans(centers)
+    assert n2 <= 2 and np.abs(c2 - centers).max() <= 1e-4 and inertia2 <= inertia * (1 + 1e-12)
+    shard = DeviceShard(pipe.flows.ptr, _lib.F32, (T - 1) * P, 2, pipe.labels.ptr)
+    c3, inertia3, n3 = fit_sharded(shard, init)
+    assert n3 == n_iter and np.abs(c3 - centers).max() <= 1e-9 and abs(inertia3 - inertia) <= 1e-9 * inertia
+    lab = pipe.labels.download(((T - 1) * P,), np.uint8)
+    cnt = np.bincount(lab, minlength=5)
+    assert cnt.sum() == (T - 1) * P and lab.max() < 5 and (cnt > 0).all()
+    pipe.close()
