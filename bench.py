@@ -80,6 +80,8 @@ def main():
 
     lib = _lib.load()
     device = local_rank if world > 1 else 0
+    if os.environ.get("OFC_BENCH_DEVICE"):            # rehearsal of N > 1 on fewer GPUs (with OFC_DIST_TRANSPORT=gloo: RCCL
+        device = int(os.environ["OFC_BENCH_DEVICE"])  # refuses two ranks on one device)
     if args.workload == "cfg4":
         if world > 1:
             sys.exit("--workload cfg4 is a single-GPU measurement (each GPU of a node would run its own stream)")
@@ -131,7 +133,8 @@ def main():
                        "width": W, "height": H, "frames": args.frames, "pairs": n_pairs_total, "k": K_CLUSTERS,
                        "lloyd_iters": int(n_iter), "flow_batch_pairs": pipe.batch,
                        "centers": [[float(v) for v in row] for row in centers], "inertia": float(inertia),
-                       "parallelism": "frames sharded x%d, RCCL all-reduce of k*(d+1)+1 f64 per Lloyd iteration" % world},
+                       "parallelism": "frames sharded x%d, all-reduce of k*(d+1)+1 f64 per Lloyd iteration, transport %s"
+                                      % (world, {"rccl": "RCCL", "gloo-host": "gloo (host fallback)", "none": "none (one rank)"}[dist.TRANSPORT])},
         }
     if not args.no_extras:
         # ---- informational legs, outside the timed region ----

@@ -235,6 +235,13 @@ int ofc_grid_kmeans_dev(int device, const uint8_t *bgr_dev, int W, int H, int n_
 int ofc_dist_unique_id(uint8_t id[OFC_UNIQUE_ID_BYTES]);          /* rank 0, then broadcast */
 int ofc_dist_init(int device, int rank, int world, const uint8_t id[OFC_UNIQUE_ID_BYTES]);
 int ofc_dist_allreduce_f64(int device, double *buf_dev, int count); /* test hook */
+/* The same exchange over a transport the CALLER provides: `fn` all-reduces `count` doubles in place across the ranks on
+ * the host (op 0 sum, 1 max, 2 min; returns 0 on success) -- gloo or MPI across nodes without xGMI/RCCL connectivity, or a
+ * pipe between processes that share one GPU (how the in-library N > 1 control flow -- all-reduced statistics, iterations
+ * behind the halt flag, the relocation exchange with its owner election -- is tested with DIFFERENT shards per rank).
+ * Every collective then costs a stream synchronisation and two small copies. */
+typedef int (*ofc_host_allreduce_fn)(double *buf, int count, int op, void *user);
+int ofc_dist_init_host(int device, int rank, int world, ofc_host_allreduce_fn fn, void *user);
 /* TEST HOOK: emulate `world` ranks that all hold the caller's shard, without a communicator (sums become world-fold,
  * max/min unchanged, rank 0): lets one GPU exercise the N>1 control flow of ofc_kmeans_fit_dev -- the result must equal
  * a single-rank fit over `world` concatenated copies of the shard.  world = 1 switches it off. */

@@ -85,6 +85,7 @@ _PROTOS = {
     "ofc_dist_unique_id": ([_vp], _i),
     "ofc_dist_init": ([_i, _i, _i, _vp], _i),
     "ofc_dist_allreduce_f64": ([_i, _vp, _i], _i),
+    "ofc_dist_init_host": ([_i, _i, _i, _vp, _vp], _i),
     "ofc_dist_loopback": ([_i], _i),
     "ofc_dist_finalize": ([], _i),
     "ofc_stream_create": ([_i, _i, _i, C.POINTER(FbParams), _i, _i, _i, C.POINTER(_vp)], _i),

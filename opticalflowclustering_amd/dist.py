@@ -26,11 +26,19 @@ def init_rccl(device, rank, world, broadcast_bytes):
     check(load().ofc_dist_init(device, rank, world, ptr(uid)))
 
 
+TRANSPORT = "none"     # what init_from_torch_env set up: "rccl", "gloo-host" (fallback / OFC_DIST_TRANSPORT=gloo) or "none"
+
+
 def init_from_torch_env(device):
-    """rendezvous through torch.distributed (gloo): returns (rank, world, barrier, allreduce_max)"""
+    """rendezvous through torch.distributed (gloo): returns (rank, world, barrier, allreduce_max).
+    The Lloyd exchange goes over RCCL (xGMI).  If the RCCL communicator cannot be set up on some rank (or
+    OFC_DIST_TRANSPORT=gloo asks for it) every rank falls back, together, to the host transport over the same gloo group
+    (ofc_dist_init_host): slower per iteration, same results."""
+    global TRANSPORT
     rank, world, _ = env_rank_world()
     if world == 1 and os.environ.get("OFC_FORCE_DIST") != "1":      # OFC_FORCE_DIST: rehearse the N>1 path on one GPU
         return 0, 1, (lambda: None), (lambda v: v)
+    import sys
     import torch
     import torch.distributed as td
     if not td.is_initialized():
@@ -41,7 +49,31 @@ def init_from_torch_env(device):
         td.broadcast(t, src=0)
         return t.numpy()
 
-    init_rccl(device, rank, world, bcast)
+    ops = {"sum": td.ReduceOp.SUM, "max": td.ReduceOp.MAX, "min": td.ReduceOp.MIN}
+
+    def gloo_allreduce(arr, op):
+        t = torch.from_numpy(np.ascontiguousarray(arr, np.float64).copy())
+        td.all_reduce(t, op=ops[op])
+        return t.numpy()
+
+    ok, err = 1.0, None
+    if os.environ.get("OFC_DIST_TRANSPORT") == "gloo":
+        ok = 0.0
+    else:
+        try:
+            init_rccl(device, rank, world, bcast)
+        except _lib.OfcError as e:
+            ok, err = 0.0, e
+    if gloo_allreduce(np.array([ok]), "min")[0] < 1.0:        # every rank takes the same branch
+        if ok and err is None and os.environ.get("OFC_DIST_TRANSPORT") != "gloo":
+            finalize()                                         # this rank did get a communicator: drop it
+        if rank == 0:
+            print("dist: RCCL not used (%s); Lloyd exchange over the gloo host transport" %
+                  (err if err is not None else "OFC_DIST_TRANSPORT=gloo or a failure on another rank"), file=sys.stderr)
+        init_host(device, rank, world, gloo_allreduce)
+        TRANSPORT = "gloo-host"
+    else:
+        TRANSPORT = "rccl"
 
     def allreduce_max(v):
         t = torch.tensor([float(v)], dtype=torch.float64)
@@ -49,6 +81,31 @@ def init_from_torch_env(device):
         return float(t.item())
 
     return rank, world, td.barrier, allreduce_max
+
+
+_HOST_CB = None      # keeps the ctypes callback alive while the library holds it
+
+
+def init_host(device, rank, world, allreduce):
+    """transport provided by the caller: allreduce(np.float64 array, op) -> reduced array, op in {'sum','max','min'} (the
+    collective signature of sharded.fit_sharded).  gloo/MPI across nodes, or a pipe between processes sharing a GPU."""
+    import ctypes as C
+    global _HOST_CB
+    proto = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_void_p)
+    names = ("sum", "max", "min")
+
+    def cb(buf, count, op, _user):
+        try:
+            a = np.ctypeslib.as_array(buf, shape=(count,))
+            a[:] = np.asarray(allreduce(a.copy(), names[op]), np.float64)
+            return 0
+        except Exception:          # never let an exception cross the C ABI
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    _HOST_CB = proto(cb)
+    check(load().ofc_dist_init_host(device, rank, world, C.cast(_HOST_CB, C.c_void_p), None))
 
 
 def finalize():

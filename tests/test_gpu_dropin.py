@@ -475,11 +475,17 @@ def test_bench_distributed_path_end_to_end_on_one_gpu():
     plain = _run_bench(["bench.py"] + common)
     dist = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                        "--master-port", str(_free_port()), "bench.py"] + common, {"OFC_FORCE_DIST": "1"})
-    for line in (plain, dist):
+    # the fallback transport (ofc_dist_init_host over the gloo group), same launcher
+    host = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), "bench.py"] + common,
+                      {"OFC_FORCE_DIST": "1", "OFC_DIST_TRANSPORT": "gloo"})
+    assert "RCCL" in dist["config"]["parallelism"] and "gloo" in host["config"]["parallelism"]
+    for line in (plain, dist, host):
         assert line["n_gpus"] == 1 and line["config"]["pairs"] == 8 and "roofline" in line
-    assert dist["config"]["lloyd_iters"] == plain["config"]["lloyd_iters"]
-    assert np.abs(np.array(dist["config"]["centers"]) - np.array(plain["config"]["centers"])).max() <= 1e-12
-    assert abs(dist["config"]["inertia"] - plain["config"]["inertia"]) <= 1e-10 * plain["config"]["inertia"]
+    for line in (dist, host):
+        assert line["config"]["lloyd_iters"] == plain["config"]["lloyd_iters"]
+        assert np.abs(np.array(line["config"]["centers"]) - np.array(plain["config"]["centers"])).max() <= 1e-12
+        assert abs(line["config"]["inertia"] - plain["config"]["inertia"]) <= 1e-10 * plain["config"]["inertia"]
 
 
 def test_streaming_ingest_at_4k_against_oracle():
@@ -541,3 +547,21 @@ def test_full_size_clip_properties():
     cnt = np.bincount(lab, minlength=5)
     assert cnt.sum() == (T - 1) * P and lab.max() < 5 and (cnt > 0).all()
     pipe.close()
+
+
+def test_bench_two_ranks_on_one_gpu_over_the_gloo_transport():
+    """bench.py with WORLD_SIZE = 2 for real: two processes under torch.distributed.run share GPU 0 (OFC_BENCH_DEVICE=0),
+    each owns half of the clip's pairs plus the halo frame, the Lloyd exchange runs over the gloo host transport
+    (RCCL refuses two ranks on one device).  Sharding, barriers, max-over-ranks timing, rank-0 JSON, teardown -- and the
+    clip-wide fit must equal the one-rank fit over the same clip"""
+    common = ["--frames", "17", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    plain = _run_bench(["bench.py", "--gpus", "1", "--no-extras"] + common)
+    two = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common,
+                     {"OFC_DIST_TRANSPORT": "gloo", "OFC_BENCH_DEVICE": "0"})
+    assert two["n_gpus"] == 2 and two["config"]["pairs"] == 16 and "gloo" in two["config"]["parallelism"]
+    assert "configs[3]" in two["config"]["workload"] and two["config"]["flow_batch_pairs"] == 8
+    assert "flow_only_mpx_s" in two["config"] and "cpu_baseline" not in two
+    assert two["config"]["lloyd_iters"] == plain["config"]["lloyd_iters"]
+    assert np.abs(np.array(two["config"]["centers"]) - np.array(plain["config"]["centers"])).max() <= 1e-9
+    assert abs(two["config"]["inertia"] - plain["config"]["inertia"]) <= 1e-9 * plain["config"]["inertia"]

@@ -262,3 +262,60 @@ def test_loopback_world_equals_fit_over_concatenated_copies(KMeans, name, world)
     assert np.array_equal(km.labels_, ref.labels_[: len(X)])
     assert np.allclose(km.cluster_centers_, ref.cluster_centers_, rtol=1e-11, atol=1e-11)
     assert abs(km.inertia_ - ref.inertia_) <= 1e-10 * ref.inertia_
+
+
+def _two_rank_library_worker(rank, conn, name, split, q):
+    """one of two processes sharing the GPU, IN-LIBRARY driver (ofc_kmeans_fit_dev: statistics all-reduced, iterations
+    enqueued behind the halt flag, relocation exchange with owner election) over a caller-provided host transport"""
+    import numpy as np
+    from opticalflowclustering_amd import _lib, dist
+    from opticalflowclustering_amd.cluster import _DT, kmeans_fit_dev
+    from tests.test_dist_gloo import make_case
+    X, C0 = make_case(name)
+    if X.dtype not in _DT:
+        X = X.astype(np.float64)
+    cut = int(len(X) * split)
+    Xs = np.ascontiguousarray(X[:cut] if rank == 0 else X[cut:])
+    fn = {"sum": np.add, "max": np.maximum, "min": np.minimum}
+
+    def allreduce(arr, op):
+        conn.send(arr)
+        other = conn.recv()
+        return fn[op](arr, other) if rank == 0 else fn[op](other, arr)     # same operand order on both ranks
+
+    dist.init_host(0, rank, 2, allreduce)
+    buf = _lib.DeviceBuffer(max(Xs.nbytes, 8), 0)
+    if len(Xs):
+        buf.upload(Xs)
+    lab = _lib.DeviceBuffer(max(len(Xs), 1), 0)
+    cen, inertia, n_iter = kmeans_fit_dev(buf.ptr, _DT[Xs.dtype], len(Xs), Xs.shape[1], C0, labels_ptr=lab.ptr)
+    labels = lab.download((len(Xs),), np.uint8) if len(Xs) else np.zeros(0, np.uint8)
+    dist.finalize()
+    q.put((rank, cen, inertia, n_iter, labels.astype(np.int32)))
+
+
+@pytest.mark.parametrize("name,split", [("uv", 0.5), ("reloc", 0.6), ("reloc", 0.9), ("rgba", 0.37), ("uv", 1.0)])
+def test_two_processes_in_library_driver_with_different_shards(name, split):
+    """the in-library N > 1 loop with REAL ranks: two processes, uneven shards (one of them empty in the last case), the
+    per-iteration exchange carried by ofc_dist_init_host's callback over a pipe.  'reloc' puts the farthest sample on
+    rank 1 (split 0.6: owner election on a rank other than 0; split 0.9: on the small shard).  Must equal the
+    single-process oracle fit: labels, iteration count, centres, inertia."""
+    import multiprocessing as mp
+    from tests.test_dist_gloo import make_case
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    c0, c1 = ctx.Pipe()
+    procs = [ctx.Process(target=_two_rank_library_worker, args=(r, c, name, split, q)) for r, c in ((0, c0), (1, c1))]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    X, C0 = make_case(name)
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, C0)
+    assert res[0][3] == res[1][3] == n_iter
+    assert np.array_equal(np.concatenate([res[0][4], res[1][4]]), lab)
+    for r in res:
+        assert np.abs(r[1] - cen).max() <= 1e-9 and abs(r[2] - inertia) <= 1e-10 * inertia
+    assert np.array_equal(res[0][1], res[1][1])
