@@ -82,12 +82,15 @@ def main():
     device = local_rank if world > 1 else 0
     if os.environ.get("OFC_BENCH_DEVICE"):            # rehearsal of N > 1 on fewer GPUs (with OFC_DIST_TRANSPORT=gloo: RCCL
         device = int(os.environ["OFC_BENCH_DEVICE"])  # refuses two ranks on one device)
-    if args.workload == "cfg4":
-        if world > 1:
-            sys.exit("--workload cfg4 is a single-GPU measurement (each GPU of a node would run its own stream)")
-        print(json.dumps(bench_cfg4(args, device)), flush=True)
-        return
     rank, world, barrier, allreduce_max = dist.init_from_torch_env(device)
+    if args.workload == "cfg4":
+        out = bench_cfg4(args, device, rank, world, barrier, allreduce_max)
+        if world > 1 or force_dist:
+            barrier()
+            dist.finalize()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
 
     n_pairs_total = args.frames - 1
     p0, p1 = shard_pairs(n_pairs_total, world, rank)
@@ -350,12 +353,16 @@ class ThreadedOracleShard:
         return float(d2[i]), i, Xc[i], int(self.labels[i])
 
 
-def bench_cfg4(args, device):
-    """BASELINE.json configs[4] on one GPU: 4K frames pushed one by one from host memory (as a decoder hands them over)
-    through the pinned double-buffered hipMemcpyAsync ingest, Farneback per pair, reduced on the device to the 14x25
-    grid-cell averaged flow (KmeanGrids' grid), then Lloyd k=8 over the cell vectors.  PCIe-inclusive by construction."""
-    from opticalflowclustering_amd import synth
-    from opticalflowclustering_amd.cluster import KMeans
+def bench_cfg4(args, device, rank=0, world=1, barrier=lambda: None, allreduce_max=lambda v: v):
+    """BASELINE.json configs[4]: a 4K stream of `--frames4k` frames pushed one by one from host memory (as a decoder hands
+    them over) through the pinned double-buffered hipMemcpyAsync ingest, Farneback per pair, reduced on the device to the
+    14x25 grid-cell averaged flow (KmeanGrids' grid), then Lloyd k=8 over all cell vectors.  PCIe-inclusive by
+    construction.  With N ranks the stream is cut into contiguous pair ranges (each rank also pushes its one halo frame)
+    and the Lloyd fit over the cell vectors is the in-library one: every rank holds its own vectors, one all-reduce per
+    iteration."""
+    from opticalflowclustering_amd import _lib, synth
+    from opticalflowclustering_amd.cluster import kmeans_fit_dev, seeded_rows_init
+    from opticalflowclustering_amd.pipeline import shard_pairs
     from opticalflowclustering_amd.stream import FlowStream
     W4, H4, n = 3840, 2160, args.frames4k
     p = synth.texture_params(0)
@@ -363,31 +370,45 @@ def bench_cfg4(args, device):
     # the eight distinct frames back and forth (0..7,6..1,0..): every consecutive pair is one motion step
     base = [synth.frame(W4, H4, *synth.population_motion(W4, H4, t, n_pop=8, seed=4)[:2], p).astype(np.uint8) for t in range(8)]
     order = list(range(8)) + list(range(6, 0, -1))
+    p0, p1 = shard_pairs(n - 1, world, rank)                  # this rank's pairs [p0, p1): frames p0 .. p1
     fs = FlowStream(W4, H4, batch_pairs=8, device=device)
+    buf = _lib.DeviceBuffer(max(p1 - p0, 1) * 350 * 8, device)
+    # the same initial centres on every rank: 8 distinct rows of the first 14 pairs' cell vectors (those pairs cycle with
+    # period 14, so every rank can compute them from frames it has anyway)
+    warm = FlowStream(W4, H4, batch_pairs=8, device=device)
+    for t in range(15):
+        warm.push(base[order[t % len(order)]])
+    init = seeded_rows_init(warm.finish().reshape(-1, 2), 8, 0)
+    warm.close()
 
     def step():
-        for t in range(n):
+        for t in range(p0, p1 + 1):
             fs.push(base[order[t % len(order)]])
         cells = fs.finish()
-        km = KMeans(n_clusters=8, init="seeded-rows", random_state=0, device=device).fit(cells.reshape(-1, 2))
-        return cells, km
+        buf.upload(cells)
+        return cells, kmeans_fit_dev(buf.ptr, _lib.F32, cells.shape[0] * 350, 2, init, device=device)
 
     for _ in range(max(args.warmup, 1)):
         step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cells, km = step()
-    dt = time.perf_counter() - t0
+        cells, (centers, inertia, n_iter) = step()
+    barrier()
+    dt = allreduce_max(time.perf_counter() - t0)
     fs.close()
+    buf.free()
+    from opticalflowclustering_amd import dist
     return {"metric": "Mpixels/s dense flow+kmeans @4K stream", "value": args.steps * (n - 1) * W4 * H4 / 1e6 / dt,
-            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 storage, f64 accumulation", "data": "synthetic, pushed from host memory (PCIe-inclusive)",
-            "config": {"workload": "BASELINE.json configs[4] on one GPU: %d-frame 4K stream, pinned double-buffered ingest, "
-                                   "Farneback, 14x25 grid-cell averaged flow, Lloyd k=8 over the cell vectors" % n,
-                       "width": W4, "height": H4, "frames": n, "pairs": n - 1, "k": 8, "lloyd_iters": int(km.n_iter_),
-                       "cell_vectors": int(cells.shape[0] * cells.shape[1]), "ms_per_frame": 1e3 * dt / args.steps / n,
-                       "upload_bytes_per_frame": W4 * H4}}
+            "config": {"workload": "BASELINE.json configs[4]: %d-frame 4K stream sharded over %d GPU(s), pinned double-buffered "
+                                   "ingest, Farneback, 14x25 grid-cell averaged flow, Lloyd k=8 over the cell vectors" % (n, world),
+                       "width": W4, "height": H4, "frames": n, "pairs": n - 1, "k": 8, "lloyd_iters": int(n_iter),
+                       "cell_vectors": int((n - 1) * 350), "ms_per_frame": 1e3 * dt / args.steps / n,
+                       "upload_bytes_per_frame": W4 * H4, "centers": [[float(v) for v in row] for row in centers],
+                       "inertia": float(inertia), "transport": dist.TRANSPORT}}
 
 
 if __name__ == "__main__":

@@ -565,3 +565,17 @@ def test_bench_two_ranks_on_one_gpu_over_the_gloo_transport():
     assert two["config"]["lloyd_iters"] == plain["config"]["lloyd_iters"]
     assert np.abs(np.array(two["config"]["centers"]) - np.array(plain["config"]["centers"])).max() <= 1e-9
     assert abs(two["config"]["inertia"] - plain["config"]["inertia"]) <= 1e-9 * plain["config"]["inertia"]
+
+
+def test_bench_cfg4_one_and_two_ranks():
+    """`bench.py --workload cfg4` (4K frames pushed from host memory, cell-averaged flow, k = 8): one rank, and the same
+    stream cut over two ranks sharing GPU 0 (gloo transport) -- the clip-wide fit over the cell vectors must agree"""
+    common = ["--workload", "cfg4", "--frames4k", "33", "--steps", "1", "--warmup", "1"]
+    one = _run_bench(["bench.py", "--gpus", "1"] + common)
+    two = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common,
+                     {"OFC_DIST_TRANSPORT": "gloo", "OFC_BENCH_DEVICE": "0"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["config"]["cell_vectors"] == 32 * 350
+    assert one["config"]["lloyd_iters"] == two["config"]["lloyd_iters"] >= 2
+    assert np.abs(np.array(one["config"]["centers"]) - np.array(two["config"]["centers"])).max() <= 1e-9
+    assert abs(one["config"]["inertia"] - two["config"]["inertia"]) <= 1e-9 * one["config"]["inertia"]
