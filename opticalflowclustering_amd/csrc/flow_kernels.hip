@@ -966,12 +966,15 @@ __device__ __forceinline__ float2 upsampled_flow(const float2 *__restrict__ s, i
 // 1/pyr_scale) instead of from a materialised upsampled copy -- K6 fused in, 16 B/px less traffic and one launch less.
 // UPS = 0: flow_in is at this level's size; 1: bilinear upsample of the coarser level with general taps; 2: the exact x2
 // pyramid (pyr_scale 0.5 on even sizes), whose taps follow a fixed parity pattern (see below)
-template <int M, int UPS>
+// STAMP: diagnostic build (tools/fi_stamps.py): s_memtime stamps around the phases of a step, summed per wave into `dbg`
+// [block][wave][8] -- where a step's cycles go; never used by the engine
+template <int M, int UPS, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
                                                       const float *__restrict__ flow_inb,
                                                       float *__restrict__ flow_outb, int W, int H,
                                                       int rows_per_block /* multiple of 16 */, UpsArgs ups,
-                                                      int tiles_x, int n_strips, int npair)
+                                                      int tiles_x, int n_strips, int npair,
+                                                      unsigned long long *__restrict__ dbg = nullptr)
 {
     constexpr int TXO = 256 - 2 * M;
     constexpr int NV = 2 * M + 4;
@@ -1080,6 +1083,17 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < BS_ROWS; r++) fln[r] = flow_in[(size_t)min(y_begin + r + 1 + M, H - 1) * W + xc];
     }
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot) {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            if (slot >= 0) acc_t[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+    stamp(-1);
     for (int y16 = y_begin; y16 < y_end; y16 += 16) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
@@ -1130,6 +1144,7 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     // a wave that is ready to issue its gathers goes first: while its SIMD neighbour grinds through a
                     // horizontal pass, all 36 requests of this step leave at once instead of trickling out between the
                     // neighbour's VALU instructions (level-0 launch 783 -> 655 us)
+                    stamp(0);                                   // 0: loop head, flow vectors / coarse taps of this step
                     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int q = 0; q < BS_ROWS; q++)            // the gathers of all four rows in flight together
@@ -1138,6 +1153,11 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
                         for (int r = 0; r < BS_ROWS; r++)
                             fln[r] = flow_in[(size_t)min(yc + BS_ROWS + r + 1 + M, H - 1) * W + xc];
+                    }
+                    stamp(1);                                   // 1: issuing the gathers
+                    if (STAMP) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        stamp(2);                               // 2: waiting for the operands
                     }
                     __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -1151,9 +1171,11 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                     coarse_taps(s0n + 2, pn[0][0], pn[0][1]);
                     coarse_taps(s0n + 3, pn[1][0], pn[1][1]);
                 }
+                stamp(7);                                       // 7: matrix arithmetic
                 // the barrier that protects `vs` from the previous step's readers sits HERE, after this step's loads and
                 // matrix arithmetic: a wave that finished its horizontal pass early starts its gathers without waiting
                 __syncthreads();
+                stamp(3);                                       // 3: first barrier
 #pragma unroll
                 for (int r = 0; r < BS_ROWS; r++) {
                     const int s_in = (4 * q4 + r + 1 + M) & 15, s_out = (4 * q4 + r + 16 - M) & 15;
@@ -1165,7 +1187,9 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
 #pragma unroll
                     for (int c = 0; c < 5; c++) ring[s_in][c] = mi[r][c];
                 }
+                stamp(4);                                       // 4: ring / vertical sums / exchange writes
                 __syncthreads();
+                stamp(5);                                       // 5: second barrier
                 __builtin_amdgcn_s_setprio(0);
                 const int y = yc + wave;
                 const int xo = x0 + 4 * lane;
@@ -1207,8 +1231,13 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                             if (4 * lane + o < TXO && xo + o < W) dst[o] = fo[o];
                     }
                 }
+                stamp(6);                                       // 6: horizontal sums + solve + stores
             }
         }
+    }
+    if (STAMP && dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = acc_t[i];
     }
 }
 
@@ -1640,6 +1669,23 @@ int launch_flow_iter_w3(const float *R, size_t frame_stride_R, const float *flow
     dim3 grid(cdiv(tx * ns, 8) * 8 * npair);
     hipLaunchKernelGGL((k_flow_iter_w3<7>), grid, dim3(256), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
                        rows_per_block, tx, ns, npair);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// diagnostic launch of the stamped build (non-UPS, winsize 15); dbg: [grid][4][8] u64, zeroed by the caller
+int launch_flow_iter_stamped(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                             int H, hipStream_t s, unsigned long long *dbg, int *grid_out)
+{
+    const int rows_per_block = flow_iter_rows(W, H, npair, 15);
+    UpsArgs u;
+    u.src = nullptr; u.sw = 0; u.sh = 0; u.mul = 1.f; u.scx = 1.0; u.scy = 1.0;
+    const int tx = cdiv(W, 256 - 14), ns = cdiv(H, rows_per_block);
+    dim3 grid(cdiv(tx * ns, 8) * 8 * npair);
+    if (grid_out) *grid_out = (int)grid.x;
+    if (dbg)
+        hipLaunchKernelGGL((k_flow_iter<7, 0, true>), grid, dim3(256), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                           rows_per_block, u, tx, ns, npair, dbg);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

@@ -655,6 +655,29 @@ int ofc_bench_flow_iters(int device, int W, int H, int n_pairs, int reps, int mo
     hipEvent_t e0, e1;
     OFC_HIP(hipEventCreate(&e0));
     OFC_HIP(hipEventCreate(&e1));
+    if (mode == 3) {            // diagnostic: the stamped build of k_flow_iter, phase shares printed to stdout
+        int grid = 0;
+        OFC_TRY(launch_flow_iter_stamped(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, s, nullptr, &grid));
+        DevBuf dbg;
+        OFC_TRY(dbg.alloc(sizeof(unsigned long long) * (size_t)grid * 4 * 8));
+        OFC_HIP(hipMemsetAsync(dbg.p, 0, dbg.bytes, s));
+        OFC_TRY(launch_flow_iter_stamped(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, s,
+                                         dbg.as<unsigned long long>(), &grid));
+        OFC_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)grid * 4 * 8);
+        OFC_HIP(hipMemcpy(h.data(), dbg.p, dbg.bytes, hipMemcpyDeviceToHost));
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all = 0;
+        for (size_t i = 0; i < h.size(); i++) { tot[i & 7] += (double)h[i]; all += (double)h[i]; }
+        static const char *name[8] = {"loop head / flow vectors", "issuing the gathers", "waiting for the operands", "first barrier",
+                                      "ring + vertical sums + exchange writes", "second barrier", "horizontal sums + solve + stores",
+                                      "matrix arithmetic"};
+        printf("k_flow_iter<7,0> stamped build, %dx%d x %d pairs: share of the waves' in-loop cycles\n", W, H, n_pairs);
+        for (int i = 0; i < 8; i++) printf("  %-42s %5.1f %%\n", name[i], 100.0 * tot[i] / all);
+        fflush(stdout);
+        *ms_out = 0.f;
+        (void)hipStreamDestroy(s);
+        return OFC_OK;
+    }
     auto two = [&]() -> int {
         if (mode == 1) return launch_flow_iter2(R.as<float>(), 5 * P, fa.as<float>(), fb.as<float>(), n_pairs, W, H, 15, s);
         if (mode == 2) {

@@ -111,6 +111,8 @@ int launch_flow_iter2(const float *R, size_t frame_stride_R, const float *flow_i
 // one iteration, 3-waves-per-SIMD form (winsize 15, flow_in at this level's size)
 int launch_flow_iter_w3(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
                         int H, int winsize, hipStream_t s, int rows_per_block = 0);
+int launch_flow_iter_stamped(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                             int H, hipStream_t s, unsigned long long *dbg, int *grid_out);
 int polyexp_default_rows(int W, int H, int nimg);
 int box_default_rows(int W, int H, int npair);
 
