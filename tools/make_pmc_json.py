@@ -21,7 +21,7 @@ for path in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 W, H = 1920, 1080
 want = {"k_polyexp": ("k_polyexp<1, false", 24 * W * H * 64, "64 x 1920x1080 images per launch"),
-        "k_flow_iter": ("k_flow_iter<7, 0>", 56 * W * H * 32, "32 x 1920x1080 pairs per launch, level-0 iteration 2/3")}
+        "k_flow_iter": ("k_flow_iter<7, 0,", 56 * W * H * 32, "32 x 1920x1080 pairs per launch, level-0 iteration 2/3")}
 rec = {"source_sha16": bench.source_sha16(), "tag": tag, "kernels": {},
        "correction": "read bytes = 2 x FETCH_SIZE x 1024 (all read requests are 128 B: TCC_EA0_RDREQ_32B = 0 and "
                      "FETCH_SIZE x 1024 = TCC_EA0_RDREQ x 64); WRITE_SIZE x 1024 exact",
