@@ -1,4 +1,5 @@
 // membench.hip -- what the HBM can do for polyexp's traffic shape (1 f32 plane read, 5 f32 planes written)
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o tools/membench   (the binary is not tracked)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,6 @@
 // readbench.hip -- read bandwidth as a function of the working-set size (does the 256 MB Infinity Cache serve re-reads
 // faster than HBM?): each launch sums a buffer of S bytes; launches repeat back to back over the same buffer.
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/readbench.hip -o tools/readbench   (the binary is not tracked)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
