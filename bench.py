@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs outside the timed region")
     ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2")
-    ap.add_argument("--frames4k", type=int, default=200, help="frames pushed per step of --workload cfg4")
+    ap.add_argument("--frames4k", type=int, default=1000, help="frames pushed per step of --workload cfg4 (configs[4]: 1000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -319,3 +319,23 @@ def test_two_processes_in_library_driver_with_different_shards(name, split):
     for r in res:
         assert np.abs(r[1] - cen).max() <= 1e-9 and abs(r[2] - inertia) <= 1e-10 * inertia
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """error behaviour of the round-2 exports: negative codes + message, nothing crosses the ABI as an exception"""
+    import ctypes as C
+    from opticalflowclustering_amd import _lib
+    lib = _lib.load()
+    assert lib.ofc_dist_init_host(0, 0, 2, None, None) == _lib.OFC_EINVAL
+    assert lib.ofc_dist_init_host(0, 3, 2, C.c_void_p(1), None) == _lib.OFC_EINVAL
+    z = np.zeros((8, 8, 5), np.float32)
+    f = np.zeros((8, 8, 2), np.float32)
+    out = np.zeros((8, 8, 2), np.float32)
+    assert lib.ofc_flow_iterate(0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 8, 8, 15, 0, 0, 0, _lib.ptr(out)) == _lib.OFC_EINVAL
+    assert lib.ofc_flow_iterate(0, None, _lib.ptr(z), _lib.ptr(f), 8, 8, 15, 1, 0, 0, _lib.ptr(out)) == _lib.OFC_EINVAL
+    # the two-iteration and three-wave kernels are built for the reference's winsize only
+    assert lib.ofc_flow_iterate(0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 8, 8, 9, 2, 1, 0, _lib.ptr(out)) == _lib.OFC_EUNSUPPORTED
+    assert b"winsize" in lib.ofc_last_error()
+    assert lib.ofc_flow_iterate(0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(f), 8, 8, 9, 1, 2, 0, _lib.ptr(out)) == _lib.OFC_EUNSUPPORTED
+    ms = C.c_float()
+    assert lib.ofc_bench_flow_iters(0, 64, 64, 0, 1, 0, C.byref(ms)) == _lib.OFC_EINVAL
