@@ -89,6 +89,12 @@ int ofc_flow_calc(ofc_flow_t *f, const uint8_t *prev_gray, const uint8_t *next_g
  * Asynchronous on the engine's stream; ofc_flow_sync() (or ofc_device_sync) completes it. */
 int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames,
                              float *flow_dev);
+/* As above, and uv_sum_dev[0..1] (device) receive sum(u), sum(v) over the n_frames-1 flow fields in float64: the column
+ * sums the clip-wide k-means needs for sklearn's centring (X.mean(axis=0), _kmeans.py:1478-1484) come out of the
+ * epilogue of the iteration that writes the field instead of an extra sweep over it (pass them to
+ * ofc_kmeans_fit_dev_stats).  OFC_EUNSUPPORTED unless winsize 15, >= 2 iterations, fused engine. */
+int ofc_flow_calc_frames_dev_stats(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames,
+                                   float *flow_dev, double *uv_sum_dev);
 int ofc_flow_sync(ofc_flow_t *f);
 
 /* streaming form of ComputeOpticalFLow (computeOpticalFlowModule.py:6-36): keeps the previous
@@ -179,6 +185,11 @@ int ofc_kmeans_predict(int device, const void *X, int dtype, int64_t N, int d, i
 int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int d, int k,
                        const double *init, int max_iter, double tol_rel, double *centers,
                        uint8_t *labels_dev, double *inertia, int *n_iter);
+/* ofc_kmeans_fit_dev with the column sums of THIS RANK'S rows supplied by the caller (host pointer, d doubles; e.g. added
+ * up from ofc_flow_calc_frames_dev_stats): the fit skips its own column-sum sweep.  colsum == NULL: as ofc_kmeans_fit_dev. */
+int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N, int d, int k,
+                             const double *init, int max_iter, double tol_rel, const double *colsum,
+                             double *centers, uint8_t *labels_dev, double *inertia, int *n_iter);
 /* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same
  * kernels, one pass per call, records returned to the host so that ANY collective (RCCL, or
  * torch.distributed/gloo across nodes) can combine the shards.  X_dev is this rank's shard. ---- */

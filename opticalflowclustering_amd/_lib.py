@@ -52,6 +52,7 @@ _PROTOS = {
     "ofc_flow_destroy": ([_vp], None),
     "ofc_flow_calc": ([_vp, _vp, _vp, _vp], _i),
     "ofc_flow_calc_frames_dev": ([_vp, _vp, _i, _vp], _i),
+    "ofc_flow_calc_frames_dev_stats": ([_vp, _vp, _i, _vp, _vp], _i),
     "ofc_flow_sync": ([_vp], _i),
     "ofc_flow_push_gray": ([_vp, _vp, _vp], _i),
     "ofc_flow_push_bgr": ([_vp, _vp, _vp, C.POINTER(_f), _vp], _i),
@@ -74,6 +75,7 @@ _PROTOS = {
     "ofc_kmeans_fit": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, C.POINTER(_d), _ip], _i),
     "ofc_kmeans_predict": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp], _i),
     "ofc_kmeans_fit_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, C.POINTER(_d), _ip], _i),
+    "ofc_kmeans_fit_dev_stats": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, _vp, C.POINTER(_d), _ip], _i),
     "ofc_lloyd_colstats_dev": ([_i, _vp, _i, _i64, _i, _vp, _i, _vp], _i),
     "ofc_lloyd_step_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
     "ofc_lloyd_inertia_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, C.POINTER(_d)], _i),

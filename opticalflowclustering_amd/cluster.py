@@ -146,13 +146,17 @@ class KMeans:
         return self.fit(X).labels_
 
 
-def kmeans_fit_dev(X_ptr, dtype, N, d, init, max_iter=300, tol=1e-4, labels_ptr=None, device=0):
-    """device-resident X (this rank's shard when a communicator is active).
+def kmeans_fit_dev(X_ptr, dtype, N, d, init, max_iter=300, tol=1e-4, labels_ptr=None, device=0, colsum=None):
+    """device-resident X (this rank's shard when a communicator is active).  colsum: this rank's column sums when the
+    caller already has them (the flow engine emits sum(u), sum(v) with the field): the fit then skips that sweep.
     -> centers (k,d), inertia, n_iter"""
     C0 = np.ascontiguousarray(init, np.float64)
     k = C0.shape[0]
     centers = np.empty((k, d), np.float64)
     inertia, n_iter = C.c_double(), C.c_int()
-    check(load().ofc_kmeans_fit_dev(device, C.c_void_p(X_ptr), dtype, N, d, k, ptr(C0), max_iter, tol, ptr(centers),
-                                    C.c_void_p(labels_ptr) if labels_ptr else None, C.byref(inertia), C.byref(n_iter)))
+    cs = np.ascontiguousarray(colsum, np.float64) if colsum is not None else None
+    if cs is not None and cs.shape != (d,):
+        raise ValueError(f"colsum must have shape ({d},)")
+    check(load().ofc_kmeans_fit_dev_stats(device, C.c_void_p(X_ptr), dtype, N, d, k, ptr(C0), max_iter, tol, ptr(cs), ptr(centers),
+                                          C.c_void_p(labels_ptr) if labels_ptr else None, C.byref(inertia), C.byref(n_iter)))
     return centers, inertia.value, n_iter.value

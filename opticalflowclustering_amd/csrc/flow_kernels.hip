@@ -10,7 +10,7 @@
 // Arithmetic follows the oracle (oracle/farneback_ref.c == SURVEY.md App. A) statement by statement.
 // Kernels that are purely memory bound keep FP contraction OFF so that they reproduce the oracle
 // bit for bit; polyexp and the box filter use FMAs / exact f64 sums (differences ~1e-7 relative).
-#include "ofc_common.h"
+#include "lloyd_common.h"     // launch_reduce_records (fixed-order sum of per-work-group records)
 
 #include <algorithm>
 #include <climits>
@@ -968,13 +968,16 @@ __device__ __forceinline__ float2 upsampled_flow(const float2 *__restrict__ s, i
 // pyramid (pyr_scale 0.5 on even sizes), whose taps follow a fixed parity pattern (see below)
 // STAMP: diagnostic build (tools/fi_stamps.py): s_memtime stamps around the phases of a step, summed per wave into `dbg`
 // [block][wave][8] -- where a step's cycles go; never used by the engine
-template <int M, int UPS, bool STAMP = false>
+// SUMS: also emit, per work-group, the f64 sums of the flow vectors it stores (`sums`: [grid][2]) -- the column sums Lloyd's
+// centring needs, taken from the last level-0 iteration's epilogue instead of from an extra 5 GB sweep over the clip
+template <int M, int UPS, bool STAMP = false, bool SUMS = false>
 __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ Rb, size_t frame_stride_R,
                                                       const float *__restrict__ flow_inb,
                                                       float *__restrict__ flow_outb, int W, int H,
                                                       int rows_per_block /* multiple of 16 */, UpsArgs ups,
                                                       int tiles_x, int n_strips, int npair,
-                                                      unsigned long long *__restrict__ dbg = nullptr)
+                                                      unsigned long long *__restrict__ dbg = nullptr,
+                                                      double *__restrict__ sums = nullptr)
 {
     constexpr int TXO = 256 - 2 * M;
     constexpr int NV = 2 * M + 4;
@@ -994,7 +997,11 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     const int tiles = tiles_x * n_strips;
     const int group = blockIdx.x / (8 * npair), rem = blockIdx.x - group * (8 * npair);
     const int pair = rem >> 3, tile = group * 8 + (rem & 7);
-    if (tile >= tiles) return;
+    if (tile >= tiles) {
+        if (SUMS && threadIdx.x < 2) sums[(size_t)blockIdx.x * 2 + threadIdx.x] = 0.0;     // padding work-group of the grid
+        return;
+    }
+    double su = 0, sv = 0;                          // SUMS: this thread's share of sum(u), sum(v)
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const int x0 = tile_x * TXO;
     const int y_begin = tile_y * rows_per_block;
@@ -1221,6 +1228,11 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
                         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
                         fo[o] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
                     }
+                    if (SUMS) {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+                            if (4 * lane + o < TXO && xo + o < W) { su += (double)fo[o].x; sv += (double)fo[o].y; }
+                    }
                     float2 *dst = flow_out + (size_t)y * W + xo;
                     if (4 * lane + 3 < TXO && xo + 3 < W && (W & 1) == 0) {      // 32 contiguous, 16-B aligned bytes
                         reinterpret_cast<float4 *>(dst)[0] = make_float4(fo[0].x, fo[0].y, fo[1].x, fo[1].y);
@@ -1238,6 +1250,16 @@ __global__ __launch_bounds__(256, 2) void k_flow_iter(const float *__restrict__ 
     if (STAMP && dbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = acc_t[i];
+    }
+    if (SUMS) {                 // fixed order: shuffle tree inside the wave, then waves 0..3
+        for (int off = 32; off >= 1; off >>= 1) {
+            su += __shfl_down(su, off, 64);
+            sv += __shfl_down(sv, off, 64);
+        }
+        __syncthreads();        // the last step's readers are done with vs
+        if (lane == 0) { vs[0][0][2 * wave] = su; vs[0][0][2 * wave + 1] = sv; }
+        __syncthreads();
+        if (tid < 2) sums[(size_t)blockIdx.x * 2 + tid] = ((vs[0][0][tid] + vs[0][0][2 + tid]) + vs[0][0][4 + tid]) + vs[0][0][6 + tid];
     }
 }
 
@@ -1259,9 +1281,15 @@ int flow_iter_rows(int W, int H, int npair, int winsize)
     return best_rows;
 }
 
+int flow_iter_max_grid(int W, int H, int npair, int winsize)
+{
+    const int rows = flow_iter_rows(W, H, npair, winsize);
+    return cdiv(cdiv(W, 256 - (winsize - 1)) * cdiv(H, rows), 8) * 8 * npair;
+}
+
 int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
                      int npair, int W, int H, int winsize, hipStream_t s, const float *coarse, int sw, int sh,
-                     float mul)
+                     float mul, double *uv_sum, double *uv_scratch, size_t uv_scratch_doubles)
 {
     if (winsize > 15) { set_error("fused iteration supports winsize <= 15 (ring of 16 rows)"); return OFC_EUNSUPPORTED; }
     if ((int64_t)W * H * 5 >= (1ll << 30)) { set_error("frame too large for 32-bit R offsets (%dx%d)", W, H); return OFC_EUNSUPPORTED; }
@@ -1269,6 +1297,16 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
     UpsArgs u;
     u.src = coarse; u.sw = sw; u.sh = sh; u.mul = mul;
     u.scx = coarse ? (double)sw / W : 1.0; u.scy = coarse ? (double)sh / H : 1.0;
+    if (uv_sum) {               // the last iteration of level 0: also sum(u), sum(v) of the field it writes -> uv_sum[2]
+        if (coarse || winsize != 15) { set_error("flow sums are emitted by the plain winsize-15 iteration only"); return OFC_EUNSUPPORTED; }
+        const int tx = cdiv(W, 256 - 14), ns = cdiv(H, rows_per_block);
+        const int grid = cdiv(tx * ns, 8) * 8 * npair;
+        if ((size_t)grid * 2 > uv_scratch_doubles) { set_error("flow sums: scratch too small (%d work-groups)", grid); return OFC_EINVAL; }
+        hipLaunchKernelGGL((k_flow_iter<7, 0, false, true>), dim3(grid), dim3(256), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                           rows_per_block, u, tx, ns, npair, nullptr, uv_scratch);
+        OFC_HIP(hipGetLastError());
+        return launch_reduce_records(uv_scratch, grid, 2, uv_sum, s, nullptr);
+    }
     dim3 block(256);
 #define OFC_FI_CASE(MM)                                                                                  \
     case 2 * MM + 1: {                                                                                   \

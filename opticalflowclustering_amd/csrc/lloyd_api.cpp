@@ -142,7 +142,7 @@ static int relocate_empty(LloydScratch &sc, const void *X, int dtype, int64_t N,
 
 static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d, int k, const double *init,
                          int max_iter, double tol_rel, double *centers, uint8_t *labels_dev,
-                         double *inertia, int *n_iter)
+                         double *inertia, int *n_iter, const double *colsum = nullptr)
 {
     OFC_REQUIRE(X && init && centers, "null pointer");
     OFC_REQUIRE(dtype >= OFC_U8 && dtype <= OFC_F64, "bad dtype %d", dtype);
@@ -169,8 +169,12 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
 
     // ---- column mean (X.mean(axis=0), _kmeans.py:1478-1484) and tol (_tolerance, :279-287) ----
     double hbuf[LLOYD_DMAX + 1], mean_h[LLOYD_DMAX];
-    OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 0, sc.partial.as<double>(), nblocks, s));
-    OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
+    if (colsum) {           // the caller already has this rank's column sums (the flow kernels' epilogue): no sweep
+        OFC_HIP(hipMemcpyAsync(tot, colsum, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    } else {
+        OFC_TRY(launch_lloyd_colstats(X, dtype, N, d, st->mean, 0, sc.partial.as<double>(), nblocks, s));
+        OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, d, tot, s));
+    }
     double nloc = (double)N;
     OFC_HIP(hipMemcpyAsync(tot + d, &nloc, sizeof(double), hipMemcpyHostToDevice, s));
     OFC_TRY(dist_allreduce_f64(tot, d + 1, DIST_SUM, s));
@@ -300,6 +304,13 @@ int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int 
                        int *n_iter)
 {
     return lloyd_fit_dev(device, X_dev, dtype, N, d, k, init, max_iter, tol_rel, centers, labels_dev, inertia, n_iter);
+}
+
+int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *init,
+                             int max_iter, double tol_rel, const double *colsum, double *centers, uint8_t *labels_dev,
+                             double *inertia, int *n_iter)
+{
+    return lloyd_fit_dev(device, X_dev, dtype, N, d, k, init, max_iter, tol_rel, centers, labels_dev, inertia, n_iter, colsum);
 }
 
 // ---- host-driven building blocks ----

@@ -233,11 +233,12 @@ struct ofc_flow {
     DevBuf prev_gray;               // streaming state
     bool have_prev = false;
     DevBuf bgr_in, vis, vis_partial, vis_stats, mean_mag;   // ofc_flow_push_bgr
+    DevBuf uv_scratch;              // per-work-group (sum u, sum v) records of the last level-0 iteration (ofc_flow_calc_frames_dev_stats)
 };
 
 namespace ofc {
 
-static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float *flow_dev)
+static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float *flow_dev, double *uv_sum_dev = nullptr)
 {
     const int npair = n_frames - 1;
     const int W = f->W, H = f->H;
@@ -284,6 +285,14 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
                         OFC_HIP(hipMemsetAsync(z, 0, sizeof(float) * 2 * P * npair, s));
                         cur = z;
                     }
+                    if (uv_sum_dev && k == 0 && l == L - 1 && plan[l] == 1 && f->prm.winsize == 15 && !(f->w3 && g.w >= f->w3_min_w)) {
+                        // the field's column sums ride in the epilogue of the iteration that writes it
+                        const size_t need = (size_t)flow_iter_max_grid(g.w, g.h, npair, f->prm.winsize) * 2;
+                        if (f->uv_scratch.bytes < need * sizeof(double)) OFC_TRY(f->uv_scratch.alloc(need * sizeof(double)));
+                        OFC_TRY(launch_flow_iter(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s, nullptr, 0, 0, 1.f,
+                                                 uv_sum_dev, f->uv_scratch.as<double>(), need));
+                        uv_sum_dev = nullptr;
+                    } else
                     if (plan[l] == 2) OFC_TRY(launch_flow_iter2(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
                     else if (f->w3 && f->prm.winsize == 15 && g.w >= f->w3_min_w)
                         OFC_TRY(launch_flow_iter_w3(R, strideR, cur, nxt, npair, g.w, g.h, f->prm.winsize, s));
@@ -308,6 +317,10 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
         }
         prevFlow = dst;
         pw = g.w; ph = g.h;
+    }
+    if (uv_sum_dev) {       // no epilogue carried them (one iteration per level, staged mode, another winsize): a sweep does
+        set_error("flow sums need the fused winsize-15 engine with at least two iterations per level");
+        return OFC_EUNSUPPORTED;
     }
     return OFC_OK;
 }
@@ -385,6 +398,19 @@ int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_fra
                 n_frames - 1, f->max_batch);
     OFC_TRY(ensure_device(f->device));
     return flow_run(f, frames_dev, n_frames, flow_dev);
+}
+
+int ofc_flow_calc_frames_dev_stats(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames, float *flow_dev, double *uv_sum_dev)
+{
+    OFC_REQUIRE(f && frames_dev && flow_dev && uv_sum_dev, "null pointer");
+    OFC_REQUIRE(n_frames >= 2 && n_frames - 1 <= f->max_batch, "n_frames-1 = %d pairs not in [1, max_batch=%d]",
+                n_frames - 1, f->max_batch);
+    OFC_TRY(ensure_device(f->device));
+    if (!f->fused || f->prm.iterations < 2) {
+        set_error("flow sums need the fused engine with at least two iterations per level");
+        return OFC_EUNSUPPORTED;
+    }
+    return flow_run(f, frames_dev, n_frames, flow_dev, uv_sum_dev);
 }
 
 hipStream_t ofc_flow_stream_internal(ofc_flow_t *f) { return f->stream; }   // for stream_api.cpp (not exported in ofc.h)

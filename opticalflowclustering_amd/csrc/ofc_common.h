@@ -104,7 +104,10 @@ int launch_flow_resize(const float *src, float *dst, int npair, int sw, int sh, 
 // coarse != nullptr: the initial flow is resize(coarse [npair][sh][sw][2], (W,H)) * mul, sampled on the fly
 int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out,
                      int npair, int W, int H, int winsize, hipStream_t s, const float *coarse = nullptr,
-                     int sw = 0, int sh = 0, float mul = 1.f);
+                     int sw = 0, int sh = 0, float mul = 1.f, double *uv_sum = nullptr, double *uv_scratch = nullptr,
+                     size_t uv_scratch_doubles = 0);
+// upper bound of the iteration kernel's grid (work-groups) for a level of this size: sizes the uv_scratch above
+int flow_iter_max_grid(int W, int H, int npair, int winsize);
 // two fused iterations flow_in -> flow_out (winsize 15; flow_in at this level's size, != flow_out); rows_per_block 0 = auto
 int launch_flow_iter2(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
                       int H, int winsize, hipStream_t s, int rows_per_block = 0);

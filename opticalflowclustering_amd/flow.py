@@ -40,9 +40,14 @@ class FlowEngine:
         check(rc)
         return flow
 
-    def calc_frames_dev(self, frames_ptr, n_frames, flow_ptr, sync=True):
-        """device pointers: n_frames resident u8 frames -> n_frames-1 flows (async unless sync)"""
-        check(load().ofc_flow_calc_frames_dev(self._h, C.c_void_p(frames_ptr), n_frames, C.c_void_p(flow_ptr)))
+    def calc_frames_dev(self, frames_ptr, n_frames, flow_ptr, sync=True, uv_sum_ptr=None):
+        """device pointers: n_frames resident u8 frames -> n_frames-1 flows (async unless sync); uv_sum_ptr: device address
+        of two doubles that receive sum(u), sum(v) of those flows (from the last iteration's epilogue)"""
+        if uv_sum_ptr:
+            check(load().ofc_flow_calc_frames_dev_stats(self._h, C.c_void_p(frames_ptr), n_frames, C.c_void_p(flow_ptr),
+                                                        C.c_void_p(uv_sum_ptr)))
+        else:
+            check(load().ofc_flow_calc_frames_dev(self._h, C.c_void_p(frames_ptr), n_frames, C.c_void_p(flow_ptr)))
         if sync:
             self.sync()
 

@@ -35,6 +35,13 @@ class ClipPipeline:
         self.frames = DeviceBuffer(self.n_frames * P, device)
         self.flows = DeviceBuffer(self.n_pairs * P * 8, device)
         self.labels = DeviceBuffer(self.n_pairs * P, device)
+        # sum(u), sum(v) per batch, written by the flow engine with the field (epilogue of the last level-0 iteration):
+        # run_kmeans adds them up in batch order instead of sweeping the 5 GB of vectors once more for the column means
+        self.n_batches = -(-self.n_pairs // self.batch)
+        self.uv_sums = DeviceBuffer(self.n_batches * 16, device)
+        self._sums_valid = False
+        p = params or FbParams()
+        self._sums_supported = p.winsize == 15 and p.iterations >= 2
 
     def synth(self, t0=0, seed=0):
         """fill the resident clip with synthetic frames t0 .. t0+n_frames-1"""
@@ -46,12 +53,15 @@ class ClipPipeline:
         assert frames.shape == (self.n_frames, self.H, self.W)
         self.frames.upload(frames)
 
-    def run_flow(self, sync=True):
+    def run_flow(self, sync=True, stats=True):
         P = self.W * self.H
+        stats = stats and self._sums_supported
         for i, p0 in enumerate(range(0, self.n_pairs, self.batch)):
             n = min(self.batch, self.n_pairs - p0)
             self.engines[i % len(self.engines)].calc_frames_dev(self.frames.ptr + p0 * P, n + 1,
-                                                                self.flows.ptr + p0 * P * 8, sync=False)
+                                                                self.flows.ptr + p0 * P * 8, sync=False,
+                                                                uv_sum_ptr=self.uv_sums.ptr + 16 * i if stats else None)
+        self._sums_valid = stats
         if sync:
             self.sync()
 
@@ -64,7 +74,13 @@ class ClipPipeline:
         -> centers (k,2), inertia, n_iter"""
         self.sync()
         N = self.n_pairs * self.W * self.H
-        return kmeans_fit_dev(self.flows.ptr, _lib.F32, N, 2, init, max_iter, tol, self.labels.ptr, self.device)
+        colsum = None
+        if self._sums_valid:
+            per_batch = self.uv_sums.download((self.n_batches, 2), np.float64)
+            colsum = np.zeros(2)
+            for b in range(self.n_batches):                 # fixed order
+                colsum += per_batch[b]
+        return kmeans_fit_dev(self.flows.ptr, _lib.F32, N, 2, init, max_iter, tol, self.labels.ptr, self.device, colsum=colsum)
 
     def sample_uv(self, idx):
         """host copy of a few (u,v) rows (for choosing the initial centres)"""
@@ -82,5 +98,5 @@ class ClipPipeline:
     def close(self):
         for e in self.engines:
             e.close()
-        for b in (self.frames, self.flows, self.labels):
+        for b in (self.frames, self.flows, self.labels, self.uv_sums):
             b.free()

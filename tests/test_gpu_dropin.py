@@ -579,3 +579,27 @@ def test_bench_cfg4_one_and_two_ranks():
     assert one["config"]["lloyd_iters"] == two["config"]["lloyd_iters"] >= 2
     assert np.abs(np.array(one["config"]["centers"]) - np.array(two["config"]["centers"])).max() <= 1e-9
     assert abs(one["config"]["inertia"] - two["config"]["inertia"]) <= 1e-9 * one["config"]["inertia"]
+
+
+@pytest.mark.parametrize("W,H,T,batch", [(640, 360, 7, 4), (457, 263, 4, 3), (1920, 1080, 5, 2)])
+def test_flow_epilogue_column_sums_feed_the_fit(W, H, T, batch):
+    """sum(u), sum(v) emitted with the field by the last level-0 iteration (ofc_flow_calc_frames_dev_stats) equal the
+    sums of the stored flow vectors, and a fit that is handed them (ofc_kmeans_fit_dev_stats: no column-sum sweep) equals
+    the fit that sweeps for them"""
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    pipe = ClipPipeline(W, H, T, batch_pairs=batch, n_engines=2)
+    pipe.synth(t0=3, seed=0)
+    pipe.run_flow(stats=True)
+    flows = pipe.flows_host().astype(np.float64)
+    sums = pipe.uv_sums.download((pipe.n_batches, 2), np.float64)
+    for b in range(pipe.n_batches):
+        want = flows[b * batch:(b + 1) * batch].reshape(-1, 2).sum(0)
+        assert np.abs(sums[b] - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (b, sums[b], want)
+    init = np.array([[-3.0, -3.0], [-1.5, 1.0], [0.0, 0.0], [1.5, -1.0], [3.0, 3.0]])
+    with_stats = pipe.run_kmeans(init)
+    pipe.run_flow(stats=False)
+    assert not pipe._sums_valid
+    without = pipe.run_kmeans(init)
+    assert with_stats[2] == without[2]
+    assert np.abs(with_stats[0] - without[0]).max() <= 1e-11 and abs(with_stats[1] - without[1]) <= 1e-11 * without[1]
+    pipe.close()
