@@ -62,6 +62,30 @@ __global__ __launch_bounds__(256) void k_copy_chunk(const v4f *__restrict__ a, v
     }
 }
 
+// chunked read: each block owns a contiguous chunk, two float4 per lane per iteration with the next pair requested ahead
+// (the Lloyd sweep's load structure)
+template <bool CHUNK>
+__global__ __launch_bounds__(256) void k_read_like_lloyd(const v4f *__restrict__ a, size_t n, float *out)
+{
+    const size_t n2 = n / 2;                                   // pairs of float4 ("quads" of (u,v) points)
+    size_t q, qe, qs;
+    if (CHUNK) {
+        const size_t per = (n2 + gridDim.x - 1) / gridDim.x;
+        q = blockIdx.x * per + threadIdx.x; qe = (blockIdx.x + 1) * per < n2 ? (blockIdx.x + 1) * per : n2; qs = 256;
+    } else {
+        q = (size_t)blockIdx.x * 256 + threadIdx.x; qe = n2; qs = (size_t)gridDim.x * 256;
+    }
+    float s = 0;
+    v4f na = {0, 0, 0, 0}, nb = {0, 0, 0, 0};
+    if (q < qe) { na = __builtin_nontemporal_load(a + 2 * q); nb = __builtin_nontemporal_load(a + 2 * q + 1); }
+    for (; q < qe; q += qs) {
+        const v4f x = na, y = nb;
+        if (q + qs < qe) { na = __builtin_nontemporal_load(a + 2 * (q + qs)); nb = __builtin_nontemporal_load(a + 2 * (q + qs) + 1); }
+        s += x.x + x.y + x.z + x.w + y.x + y.y + y.z + y.w;
+    }
+    if (s == 12345.678f) out[0] = s;
+}
+
 template <class F> float timeit(F f, int iters)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -92,6 +116,8 @@ int main()
         RUN("copy chunked nt-both", 2.0 * bytes, hipLaunchKernelGGL((k_copy_chunk<true, true>), dim3(g), dim3(256), 0, 0, a, b, n))
         RUN("read u4", 1.0 * bytes, hipLaunchKernelGGL((k_read<4, false>), dim3(g), dim3(256), 0, 0, a, n, o))
         RUN("read u8 nt", 1.0 * bytes, hipLaunchKernelGGL((k_read<8, true>), dim3(g), dim3(256), 0, 0, a, n, o))
+        RUN("read lloyd-like strided", 1.0 * bytes, hipLaunchKernelGGL((k_read_like_lloyd<false>), dim3(g), dim3(256), 0, 0, a, n, o))
+        RUN("read lloyd-like chunked", 1.0 * bytes, hipLaunchKernelGGL((k_read_like_lloyd<true>), dim3(g), dim3(256), 0, 0, a, n, o))
         RUN("write", 1.0 * bytes, hipLaunchKernelGGL((k_write<false>), dim3(g), dim3(256), 0, 0, b, n))
         RUN("write nt", 1.0 * bytes, hipLaunchKernelGGL((k_write<true>), dim3(g), dim3(256), 0, 0, b, n))
     }
