@@ -41,7 +41,9 @@ class ClipPipeline:
         self.uv_sums = DeviceBuffer(self.n_batches * 16, device)
         self._sums_valid = False
         p = params or FbParams()
-        self._sums_supported = p.winsize == 15 and p.iterations >= 2
+        import os
+        experimental = any(os.environ.get(v, "0") not in ("", "0") for v in ("OFC_FLOW_FUSE2", "OFC_FLOW_W3", "OFC_FLOW_STAGED"))
+        self._sums_supported = p.winsize == 15 and p.iterations >= 2 and not experimental   # those builds carry no sums
 
     def synth(self, t0=0, seed=0):
         """fill the resident clip with synthetic frames t0 .. t0+n_frames-1"""
