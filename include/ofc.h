@@ -92,7 +92,8 @@ int ofc_flow_calc_frames_dev(ofc_flow_t *f, const uint8_t *frames_dev, int n_fra
 /* As above, and uv_sum_dev[0..1] (device) receive sum(u), sum(v) over the n_frames-1 flow fields in float64: the column
  * sums the clip-wide k-means needs for sklearn's centring (X.mean(axis=0), _kmeans.py:1478-1484) come out of the
  * epilogue of the iteration that writes the field instead of an extra sweep over it (pass them to
- * ofc_kmeans_fit_dev_stats).  OFC_EUNSUPPORTED unless winsize 15, >= 2 iterations, fused engine. */
+ * ofc_kmeans_fit_dev_stats).  Engines without that epilogue (one iteration per level, another winsize, the staged or
+ * experimental kernels) form the same two sums with one sweep over the finished field: the call always succeeds. */
 int ofc_flow_calc_frames_dev_stats(ofc_flow_t *f, const uint8_t *frames_dev, int n_frames,
                                    float *flow_dev, double *uv_sum_dev);
 int ofc_flow_sync(ofc_flow_t *f);
@@ -190,6 +191,14 @@ int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int 
 int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N, int d, int k,
                              const double *init, int max_iter, double tol_rel, const double *colsum,
                              double *centers, uint8_t *labels_dev, double *inertia, int *n_iter);
+/* How the last ofc_kmeans_fit_dev[_stats] on `device` swept its samples (no reference counterpart: sklearn's Lloyd,
+ * _k_means_lloyd.pyx:23-218, reads every sample in every iteration).  For a float32 d=2 stream (the per-pixel (u,v) vectors
+ * of computeOpticalFlow.py:99-101's field) of >= 2^20 samples and k <= 8 the label-less iterations run over 64-sample
+ * tiles; a tile whose (u,v) bounding box lies inside one Voronoi cell of the current centres contributes its cached sum
+ * without being read (exact: same labels, same n_iter, centres equal to rounding).  out6 = [tile sweeps, of them pruned,
+ * tiles tested by the pruned sweeps, tiles they skipped, probe sweeps, reserved].  Environment: OFC_LLOYD_PRUNE=0 switches
+ * the tile sweeps off, 2 enables them for any N, 3 also forces every one of them to run pruned. */
+int ofc_lloyd_prune_stats(int device, double *out6);
 /* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same
  * kernels, one pass per call, records returned to the host so that ANY collective (RCCL, or
  * torch.distributed/gloo across nodes) can combine the shards.  X_dev is this rank's shard. ---- */

@@ -157,6 +157,11 @@ def main(argv=None):
     parts = str(dirs).replace("\\", "/").rstrip("/").split("/")
     name = parts[1] if len(parts) > 1 else parts[0]                         # :379 dirs.split('/')[1]
     filepathcsv = os.path.join("OutCSV", name + ".csv")                     # :377-379
+    # the reference's cluster_colors opens `-f <csv>` in append mode for every cell and writes nothing to it
+    # (:320-330: the writerow calls are commented out), so a run leaves that file behind, created if missing, untouched
+    # otherwise; the hues go to OutCSV/<name>.csv
+    with open(args["csv"], "a", newline=""):
+        pass
     process_video(args["path"], args["clusters"], filepathcsv, device=args["device"], init=args["init"], seed=args["seed"])
 
 

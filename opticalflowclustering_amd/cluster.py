@@ -160,3 +160,12 @@ def kmeans_fit_dev(X_ptr, dtype, N, d, init, max_iter=300, tol=1e-4, labels_ptr=
     check(load().ofc_kmeans_fit_dev_stats(device, C.c_void_p(X_ptr), dtype, N, d, k, ptr(C0), max_iter, tol, ptr(cs), ptr(centers),
                                           C.c_void_p(labels_ptr) if labels_ptr else None, C.byref(inertia), C.byref(n_iter)))
     return centers, inertia.value, n_iter.value
+
+
+def prune_stats(device=0):
+    """how the last kmeans_fit_dev on `device` swept its samples (ofc_lloyd_prune_stats): tile sweeps, how many of them
+    pruned, and the share of tiles the pruned sweeps did not have to read"""
+    out = np.zeros(6, np.float64)
+    check(load().ofc_lloyd_prune_stats(device, ptr(out)))
+    return {"tile_sweeps": int(out[0]), "pruned_sweeps": int(out[1]), "probe_sweeps": int(out[4]),
+            "skip_fraction": float(out[3] / out[2]) if out[2] > 0 else 0.0}

@@ -6,6 +6,10 @@ Reference lines: color_kmeans.py:14-145.  All pixel arithmetic runs on the MI355
 Conscious deviations:
   * KMeans seeding is deterministic ('seeded-rows', seed 0) instead of unseeded k-means++ (D.8);
     irrelevant for the documented k=1.  `--init k-means++ --seed N` gives sklearn's seeding for RandomState(N).
+  * a centre component that rounds to zero from below prints as `0.`, not `-0.` (`np.rint(c) + 0.0`, also in
+    color_kmeansChange.py and color_kmeans_script.py).  The reference's recorded CSVs do hold `-0.` entries
+    (cluster_centers_copy.csv): there the sign of zero is rounding noise of sklearn's centred float64 means (a centre of
+    -1e-16), nothing downstream reads it, and numeric comparison of the column is unaffected.
   * the CSV header is written when the OUTPUT csv is empty; the reference stats a hard-coded
     'cluster_centers.csv' in the CWD and raises if it is absent (D.2)."""
 import argparse

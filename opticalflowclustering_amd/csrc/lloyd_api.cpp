@@ -23,6 +23,8 @@ static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC
 // pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
     DevBuf state, partial, tot, tot_local, excl, far, labels;
+    DevBuf tile_box, tile_sum;           // lloyd_tiles.hip: 16 + 16 B per 64-sample tile, rebuilt by every fit's iteration 0
+    double prune_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last fit, see ofc_lloyd_prune_stats
     LloydStatus *status = nullptr;       // pinned, device-visible; one slot per iteration of a window
     LloydStatus *status_dev = nullptr;
     hipStream_t stream = nullptr;
@@ -31,7 +33,7 @@ struct LloydScratch {
     int init()
     {
         if (ready) return OFC_OK;
-        constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1 + LLOYD_DMAX;
+        constexpr int NVMAX = LLOYD_NVMAX;
         OFC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         OFC_TRY(state.alloc(sizeof(LloydState)));
         OFC_TRY(partial.alloc(sizeof(double) * 2048 * NVMAX));
@@ -45,6 +47,18 @@ struct LloydScratch {
         return OFC_OK;
     }
 };
+
+// OFC_LLOYD_PRUNE: 0 = off (every sweep is k_lloyd_assign's), 1 = auto (default: tile sweeps for f32 d=2 k<=8 streams of
+// >= 2^20 samples, pruning switched on and off by the device-side policy in k_lloyd_update), 2 = as auto for any N,
+// 3 = every tile sweep after the first runs pruned whatever the share of tiles that pass (tests: worst cases)
+static int prune_policy_for(int dtype, int64_t N, int d, int k)
+{
+    if (!lloyd_tiles_supported(dtype, d, k) || N < 64) return LLOYD_PRUNE_OFF;
+    const char *e = getenv("OFC_LLOYD_PRUNE");
+    const int v = (e && e[0] >= '0' && e[0] <= '3' && !e[1]) ? e[0] - '0' : LLOYD_PRUNE_AUTO;
+    if (v == LLOYD_PRUNE_AUTO && N < (1ll << 20)) return LLOYD_PRUNE_OFF;
+    return v;
+}
 
 static LloydScratch &scratch_for(int device)
 {
@@ -192,7 +206,16 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     double c0[LLOYD_KMAX * LLOYD_DMAX];
     for (int j = 0; j < k * d; j++) c0[j] = init[j] - mean_h[j % d];
     OFC_HIP(hipMemcpyAsync(st->centers, c0, sizeof(double) * k * d, hipMemcpyHostToDevice, s));
-    OFC_TRY(launch_lloyd_set_centers(st, k, d, s));
+    const int prune = prune_policy_for(dtype, N, d, k);
+    if (prune) {
+        const size_t need = (size_t)(N >> 6) * 16;
+        if (sc.tile_box.bytes < need) {
+            OFC_TRY(sc.tile_box.alloc(need));
+            OFC_TRY(sc.tile_sum.alloc(need));
+        }
+    }
+    for (double &v : sc.prune_stats) v = 0;
+    OFC_TRY(launch_lloyd_set_centers(st, k, d, s, prune));
     // ---- Lloyd iterations ----
     // sklearn stops on `labels == labels_old` (strict) before it looks at the centre shift (_kmeans.py:716-728).  While
     // no cluster is empty that test is redundant: equal labels give bit-equal sums (fixed reduction order), hence
@@ -208,6 +231,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     // finds st->halt set and does nothing.  One host round trip per window instead of one per iteration (18 us each -- a tenth of an
     // iteration on a 1/8 shard); every rank takes the same decisions because they derive from all-reduced totals.
     bool strict = false, labelled = false, stop = false;
+    const bool trace = getenv("OFC_LLOYD_TRACE") != nullptr;
     int it = 0;
     const int *halt = &st->halt;
     double *tot_local = dist_has_comm() ? sc.tot_local.as<double>() : tot;
@@ -218,20 +242,40 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
         window = std::min(2 * window, LLOYD_WINDOW);
         for (int w = 0; w < nwin; w++) sc.status[w].valid = 0;
         for (int w = 0; w < nwin; w++) {
-            OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
-                                        labelled ? 1 : 3, it + w == 0, s));
+            // label-less sweeps of a (u,v) stream go tile by tile: iteration 0 builds the tile metadata, the later ones
+            // run in the mode k_lloyd_update chose from the previous iteration's tile counts (lloyd_tiles.hip)
+            const int tiles = (prune && !labelled) ? (it + w == 0 ? 1 : 2) : 0;
+            if (tiles)
+                OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.partial.as<double>(),
+                                           nblocks, tiles == 1, it + w == 0, s));
+            else
+                OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
+                                            labelled ? 1 : 3, it + w == 0, s));
             // with a communicator the local record goes to its own buffer and the collective writes `tot`: an iteration
             // behind the halt flag then re-reduces the same local records into the same totals (in place it would sum
             // the totals of all ranks again, and a stalled iteration's `tot` is what relocate_empty reads)
             OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, NV, tot_local, s, halt));
             OFC_TRY(dist_allreduce_f64(tot_local, tot, NV, DIST_SUM, s));
-            OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, labelled, it + w == 0, Ng, tol_rel, sc.status_dev + w, s));
+            OFC_TRY(launch_lloyd_update(st, tot, k, d, 0, labelled, it + w == 0, Ng, tol_rel, sc.status_dev + w, s, tiles));
         }
         OFC_HIP(hipStreamSynchronize(s));
         int done = nwin;                      // iterations of this window that really ran
         for (int w = 0; w < nwin; w++) {
             LloydStatus &S = sc.status[w];
             if (!S.valid) { set_error("internal: Lloyd iteration %d did not run", it + w); return OFC_EHIP; }
+            if (trace)
+                fprintf(stderr, "[ofc lloyd] it %d tiles_mode %d tested %.0f pure %.0f shift %.3e empty %d\n", it + w,
+                        S.tiles_mode, S.tiles_tested, S.tiles_pure, S.shift_tot, S.n_empty);
+            if (S.tiles_mode != -1) {
+                sc.prune_stats[0] += 1;                                   // sweeps that went tile by tile
+                if (S.tiles_mode == LLOYD_TILES_PRUNED) {
+                    sc.prune_stats[1] += 1;                               // ... of them pruned
+                    sc.prune_stats[2] += S.tiles_tested;                  // tiles tested / skipped by the pruned sweeps
+                    sc.prune_stats[3] += S.tiles_pure;
+                } else if (S.tiles_mode == LLOYD_TILES_PROBE) {
+                    sc.prune_stats[4] += 1;
+                }
+            }
             if (S.n_empty > 0) {              // the device stalled here; iterations w+1.. of the window were no-ops
                 const bool was_labelled = labelled;
                 if (!labelled) {   // materialise this iteration's labels (st->centers is still the E-step's input)
@@ -304,6 +348,17 @@ int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int 
                        int *n_iter)
 {
     return lloyd_fit_dev(device, X_dev, dtype, N, d, k, init, max_iter, tol_rel, centers, labels_dev, inertia, n_iter);
+}
+
+/* see include/ofc.h */
+int ofc_lloyd_prune_stats(int device, double *out6)
+{
+    OFC_REQUIRE(out6, "null pointer");
+    OFC_TRY(ensure_device(device));
+    LloydScratch &sc = scratch_for(device);
+    std::lock_guard<std::mutex> lock(sc.mu);
+    for (int i = 0; i < 6; i++) out6[i] = sc.prune_stats[i];
+    return OFC_OK;
 }
 
 int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N, int d, int k, const double *init,

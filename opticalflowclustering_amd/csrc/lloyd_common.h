@@ -16,7 +16,17 @@ struct LloydState {
     double tol;                                   // sklearn's tol (mean column variance * tol_rel), set by iteration 0
     int halt;                                     // set by k_lloyd_update on convergence / empty cluster: the iterations
     int pad;                                      // that were enqueued speculatively behind it become no-ops
+    // tile pruning (lloyd_tiles.hip): decided on the device, iteration by iteration, from the all-reduced tile counts
+    int prune_policy;                             // LLOYD_PRUNE_*: set by the host before iteration 0
+    int prune_mode;                               // how the NEXT k_lloyd_tiles sweep runs: LLOYD_TILES_*
+    int prune_cooldown, prune_backoff;            // full sweeps left before the next probe / its current spacing
 };
+
+// how a k_lloyd_tiles sweep treats the 64-sample tiles
+enum { LLOYD_TILES_FULL = 0,      // every tile sample by sample (no metadata read)
+       LLOYD_TILES_PRUNED = 1,    // box test per tile: cached sums for tiles wholly inside one Voronoi cell, the rest by sample
+       LLOYD_TILES_PROBE = 2 };   // box test only counted, every tile still by sample (decides whether to switch to PRUNED)
+enum { LLOYD_PRUNE_OFF = 0, LLOYD_PRUNE_AUTO = 1, LLOYD_PRUNE_ON = 2, LLOYD_PRUNE_ALWAYS = 3 };
 
 // written by k_lloyd_update into pinned host memory once per iteration (one slot per iteration of a window)
 struct LloydStatus {
@@ -29,6 +39,9 @@ struct LloydStatus {
     double tol;
     double counts[LLOYD_KMAX];
     double sqsum[LLOYD_DMAX];     // sum (x-mean)^2 per column (first iteration only)
+    double tiles_tested, tiles_pure;   // k_lloyd_tiles: tiles box-tested (or checked for uniform labels while the metadata
+    int tiles_mode;                    // is built) / found inside one cell; mode the sweep ran in (-1: not a tile sweep)
+    int pad;
 };
 
 int lloyd_kmax(int k);
@@ -39,16 +52,25 @@ int launch_reduce_records(const double *partial, int nblocks, int nv, double *ou
                           const int *halt = nullptr);
 // mode 0: labels only; 1: labels + M-step record (+ column sums of (x-mean)^2 when first != 0); 2: labels + inertia;
 // 3: M-step record only (labels untouched, n_changed = 0)
-// record = [kmax*d sums][kmax counts][n_changed][LLOYD_DMAX squared sums]
+// record = [kmax*d sums][kmax counts][n_changed][LLOYD_DMAX squared sums][tiles tested][tiles pure]
 int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const LloydState *st,
                         uint8_t *labels, double *partial, int nblocks, int mode, int first, hipStream_t s);
-inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + 1 + LLOYD_DMAX; }
+constexpr int LLOYD_REC_EXTRA = 1 + LLOYD_DMAX + 2;     // slots behind the sums and counts
+constexpr int LLOYD_NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + LLOYD_REC_EXTRA;
+inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + LLOYD_REC_EXTRA; }
+// (u,v) stream (f32, d = 2, k <= 8) in 64-sample tiles, see lloyd_tiles.hip.  build: iteration 0 -- every tile by sample,
+// writes box[N/64] (lo_u, lo_v, hi_u, hi_v) and tsum[N/64] (sum of the centred samples) and counts label-uniform tiles;
+// otherwise the sweep runs in st->prune_mode.  Record layout as launch_lloyd_assign's mode 3.
+bool lloyd_tiles_supported(int dtype, int d, int k);
+int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum,
+                       double *partial, int nblocks, int build, int first, hipStream_t s);
 // labelled: tot's n_changed slot is meaningful (mode 1); first: iteration 0, which also fixes st->tol from the
 // column sums of (x-mean)^2 in tot, n_total samples and tol_rel
+// tiles: 0 = the sweep was not a k_lloyd_tiles one, 1 = it built the tile metadata, 2 = it ran in st->prune_mode
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
-                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s);
+                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s, int tiles = 0);
 constexpr int LLOYD_WINDOW = 16;    // most iterations enqueued per host synchronisation (windows grow 4, 8, 16, 16, ...)
-int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s);
+int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s, int prune_policy = 0);
 int launch_lloyd_inertia(const void *X, int dtype, int64_t N, int d, const LloydState *st,
                          const uint8_t *labels, double *partial, int nblocks, hipStream_t s);
 int launch_lloyd_farthest(const void *X, int dtype, int64_t N, int d, const LloydState *st,

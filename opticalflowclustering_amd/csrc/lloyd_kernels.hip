@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_lloyd_assign(const T *__restrict__ X, i
     const int k = KMAX <= 8 ? KMAX : k_arg;
     constexpr bool ACCUM = (MODE == 1 || MODE == 3), LABELS = (MODE != 3);
     if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
-    constexpr int NV = KMAX * D + KMAX + 1 + LLOYD_DMAX;     // [sums][counts][changed][sum (x-mean)^2 per column]
+    constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;    // [sums][counts][changed][sum (x-mean)^2 per column][tile counts: 0 here]
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                       // [k*D][256]
     unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
@@ -376,14 +376,14 @@ __device__ inline double np_sum_small_dev(const double *a, int n)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g, int k, int d, int kmax,
                                int after_reloc, int labelled, int first, double n_total, double tol_rel,
-                               LloydStatus *status /* pinned host */)
+                               LloydStatus *status /* pinned host */, int tiles)
 {
     // one lane does the (tiny, strictly ordered) arithmetic; all 64 first stage its inputs in LDS so that it does not
     // walk through ~150 dependent global loads (8.6 -> 4 us per iteration, which matters on a 1/8 shard)
-    constexpr int NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + 1 + LLOYD_DMAX;
+    constexpr int NVMAX = LLOYD_NVMAX;
     __shared__ double tot[NVMAX], cold[LLOYD_KMAX * LLOYD_DMAX], cnew[LLOYD_KMAX * LLOYD_DMAX];
     __shared__ int s_halt;
-    const int NV = kmax * d + kmax + 1 + LLOYD_DMAX;
+    const int NV = kmax * d + kmax + LLOYD_REC_EXTRA;
     for (int i = threadIdx.x; i < NV; i += blockDim.x) tot[i] = tot_g[i];
     for (int i = threadIdx.x; i < k * d; i += blockDim.x) cold[i] = st->centers[i];
     if (threadIdx.x == 0) s_halt = st->halt;
@@ -406,6 +406,8 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
         status->converged = 0;
         status->strict = 0;
         for (int j = 0; j < k; j++) status->counts[j] = w[j];
+        status->tiles_mode = -1;
+        status->tiles_tested = status->tiles_pure = 0;
         __threadfence_system();
         status->valid = 1;
         return;
@@ -457,6 +459,41 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
     const int strict = labelled && n_changed == 0.0;
     const int converged = strict || tot_shift <= tol;
     st->halt = converged;
+    // ---- how the next tile sweep runs (lloyd_tiles.hip).  Every rank sees the same all-reduced counts, so every rank
+    // takes the same decision.  A pruned sweep costs about (metadata 6 %) + 1.2 x (share of tiles it still walks by
+    // sample) of a full one: it pays while about a third of the tiles pass the box test; a sweep that is switched off is
+    // re-examined by a PROBE (box tests counted, nothing skipped) after 6, 12, 24, ... full sweeps.
+    status->tiles_mode = -1;
+    status->tiles_tested = status->tiles_pure = 0;
+    if (tiles) {
+        const double tested = tot[kmax * d + kmax + 1 + LLOYD_DMAX], pure = tot[kmax * d + kmax + 2 + LLOYD_DMAX];
+        const double frac = tested > 0 ? pure / tested : 0.0;
+        const int ran = tiles == 1 ? -2 : st->prune_mode;       // -2: the sweep that built the metadata
+        int next = ran;
+        if (st->prune_policy == LLOYD_PRUNE_ALWAYS) {
+            next = LLOYD_TILES_PRUNED;
+        } else if (ran == -2) {           // `pure` = tiles with uniform labels: an upper bound of what the box test passes
+            next = frac >= 0.5 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
+            st->prune_backoff = 6;
+            st->prune_cooldown = st->prune_backoff;
+        } else if (ran == LLOYD_TILES_PRUNED) {
+            if (frac < 0.3) {
+                next = LLOYD_TILES_FULL;
+                st->prune_cooldown = st->prune_backoff;
+                st->prune_backoff *= 2;
+            }
+        } else if (ran == LLOYD_TILES_PROBE) {
+            next = frac >= 0.45 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
+            st->prune_cooldown = st->prune_backoff;
+            st->prune_backoff *= 2;
+        } else {                          // a full sweep
+            if (--st->prune_cooldown <= 0) next = LLOYD_TILES_PROBE;
+        }
+        st->prune_mode = next;
+        status->tiles_mode = ran;
+        status->tiles_tested = tested;
+        status->tiles_pure = pure;
+    }
     status->n_changed = n_changed;
     for (int f = 0; f < d; f++) status->sqsum[f] = tot[kmax * d + kmax + 1 + f];
     status->shift_tot = tot_shift;
@@ -470,9 +507,12 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
 }
 
 // sets centres (centred) + |c|^2 from host-provided values
-__global__ void k_lloyd_set_centers(LloydState *st, int k, int d)
+__global__ void k_lloyd_set_centers(LloydState *st, int k, int d, int prune_policy)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->prune_policy = prune_policy;
+    st->prune_mode = LLOYD_TILES_FULL;
+    st->prune_cooldown = st->prune_backoff = 6;
     for (int j = 0; j < k; j++) {
         double acc = st->centers[j * d] * st->centers[j * d];
         for (int f = 1; f < d; f++) acc = fma(st->centers[j * d + f], st->centers[j * d + f], acc);
@@ -654,17 +694,17 @@ int launch_reduce_records(const double *partial, int nblocks, int nv, double *ou
 }
 
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
-                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s)
+                        double n_total, double tol_rel, LloydStatus *status, hipStream_t s, int tiles)
 {
     hipLaunchKernelGGL(k_lloyd_update, dim3(1), dim3(64), 0, s, st, tot, k, d, lloyd_kmax(k), after_reloc, labelled,
-                       first, n_total, tol_rel, status);
+                       first, n_total, tol_rel, status, tiles);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }
 
-int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s)
+int launch_lloyd_set_centers(LloydState *st, int k, int d, hipStream_t s, int prune_policy)
 {
-    hipLaunchKernelGGL(k_lloyd_set_centers, dim3(1), dim3(64), 0, s, st, k, d);
+    hipLaunchKernelGGL(k_lloyd_set_centers, dim3(1), dim3(64), 0, s, st, k, d, prune_policy);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

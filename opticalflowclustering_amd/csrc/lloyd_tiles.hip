@@ -1,0 +1,300 @@
+// lloyd_tiles.hip -- Lloyd sweeps over a resident (u,v) field (f32, d = 2, k <= 8) that do not re-read what cannot
+// change its cluster (round 3).  Semantics stay sklearn's Lloyd (_kmeans.py:624-752, _k_means_lloyd.pyx:23-218) as
+// lloyd_api.cpp restates it; this file only changes HOW the label-less M-step record of an iteration is formed.
+//
+// The samples are cut into tiles of 64 consecutive ones (512 B; a row segment of the flow field, whose vectors are
+// close to each other inside a motion population).  Iteration 0 walks every sample and leaves per tile
+//     box[t]  = (min u, min v, max u, max v)      f32, 16 B
+//     tsum[t] = sum over the tile of (x - mean)   f64 x 2, 16 B      (the mean is fixed for the whole fit)
+// From then on a tile is tested before it is read: D_j(x) - D_j'(x) = (|c_j|^2 - |c_j'|^2) + 2 x.(c_j' - c_j) is linear
+// in x, so its maximum over the box sits at a corner; if it is negative (by a margin far above the rounding of the
+// sample-by-sample arithmetic) for every j' != j, every sample of the tile has label j whatever its position in the
+// box, and the tile contributes tsum[t] and 64 to cluster j without being read.  No drift tracking, no runner-up
+// distances (round 2's Hamerly attempt lost on exactly those).  Tiles that fail the test are walked sample by sample
+// by the same wave, 16 lanes per tile, four points per lane -- the arithmetic of k_lloyd_assign's mode 3.
+// The final E-step (labels, inertia) stays a full sweep of k_lloyd_assign: labels are the argmin against the final
+// centres sample by sample.
+//
+// Deterministic: a wave owns a fixed set of tile groups, every lane adds into its private LDS column in a fixed order,
+// columns and work-groups are folded in a fixed order (as in lloyd_kernels.hip).  The sums differ from the unpruned
+// sweep's in the last bits only (another summation order): centres agree to ~1e-15, labels and n_iter are the same
+// (tests/test_gpu_lloyd.py, bench.py's extras).
+#include "lloyd_common.h"
+
+namespace ofc {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// value of lane (l + N) % 16 of the same 16-lane row (DPP row_ror: no LDS, no address register)
+template <int N> __device__ __forceinline__ int row_ror(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false);
+}
+template <int N> __device__ __forceinline__ float row_ror(float v) { return __int_as_float(row_ror<N>(__float_as_int(v))); }
+template <int N> __device__ __forceinline__ double row_ror(double v)
+{
+    return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
+}
+// all-reduce over the 16 lanes of a row; every lane ends with the bit-identical result (each step combines a pair
+// symmetrically)
+__device__ __forceinline__ float row_min(float v)
+{
+    v = fminf(v, row_ror<8>(v)); v = fminf(v, row_ror<4>(v)); v = fminf(v, row_ror<2>(v)); return fminf(v, row_ror<1>(v));
+}
+__device__ __forceinline__ float row_max(float v)
+{
+    v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
+}
+__device__ __forceinline__ int row_min(int v)
+{
+    v = min(v, row_ror<8>(v)); v = min(v, row_ror<4>(v)); v = min(v, row_ror<2>(v)); return min(v, row_ror<1>(v));
+}
+__device__ __forceinline__ int row_max(int v)
+{
+    v = max(v, row_ror<8>(v)); v = max(v, row_ror<4>(v)); v = max(v, row_ror<2>(v)); return max(v, row_ror<1>(v));
+}
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
+}
+
+// BUILD: iteration 0 (every tile by sample, metadata written, label-uniform tiles counted).
+template <int KMAX, bool BUILD>
+__global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X, int64_t N,
+                                                     const LloydState *__restrict__ st, v4f *__restrict__ box,
+                                                     v2d *__restrict__ tsum, double *__restrict__ partial, int first)
+{
+    constexpr int D = 2, k = KMAX;
+    constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;
+    if (st->halt) return;               // speculatively enqueued behind the iteration that converged (uniform)
+    const int mode = BUILD ? LLOYD_TILES_FULL : st->prune_mode;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sacc = reinterpret_cast<double *>(smem);                             // [k*D][256]
+    unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
+    __shared__ unsigned s_tiles[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
+    double c[KMAX * D], cn[KMAX], m[D];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+        cn[j] = st->cn[j];
+#pragma unroll
+        for (int f = 0; f < D; f++) c[j * D + f] = st->centers[j * D + f];
+    }
+#pragma unroll
+    for (int f = 0; f < D; f++) m[f] = st->mean[f];
+    for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
+    for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
+    double sq[D] = {0, 0};
+    unsigned n_tested = 0, n_pure = 0;
+
+    auto label_of = [&](const double (&x)[D]) {
+        double best = 0;
+        int label = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            const double dj = cn[j] - 2.0 * fma(x[1], c[j * D + 1], x[0] * c[j * D]);
+            if (j == 0 || dj < best) { best = dj; label = j; }
+        }
+        return label;
+    };
+    auto accumulate = [&](int l, double x0, double x1, unsigned n) {
+        sacc[(l * D) * 256 + tid] += x0;
+        sacc[(l * D + 1) * 256 + tid] += x1;
+        scnt[l * 256 + tid] += n;
+    };
+    // four consecutive samples of tile t (this lane's quad of its row's tile)
+    auto walk = [&](int64_t t, const v4f a, const v4f b) {
+        double x[4][D];
+        x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
+        x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
+        int nl[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            x[p][0] -= m[0];
+            x[p][1] -= m[1];
+            nl[p] = label_of(x[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) accumulate(nl[p], x[p][0], x[p][1], 1u);
+        if (first) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                sq[0] += x[p][0] * x[p][0];
+                sq[1] += x[p][1] * x[p][1];
+            }
+        }
+        if (BUILD) {
+            const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
+            const float lv = row_min(fminf(fminf(a.y, a.w), fminf(b.y, b.w)));
+            const float hu = row_max(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)));
+            const float hv = row_max(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)));
+            const double su = row_sum((x[0][0] + x[1][0]) + (x[2][0] + x[3][0]));
+            const double sv = row_sum((x[0][1] + x[1][1]) + (x[2][1] + x[3][1]));
+            const int l0 = row_min(min(min(nl[0], nl[1]), min(nl[2], nl[3])));
+            const int l1 = row_max(max(max(nl[0], nl[1]), max(nl[2], nl[3])));
+            if (r16 == 0) {
+                v4f bx = {lu, lv, hu, hv};
+                if (!(su == su && sv == sv)) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                box[t] = bx;                        // a tile with a NaN in it never passes the box test
+                tsum[t] = v2d{su, sv};
+                n_tested += 1u;
+                n_pure += (l0 == l1);
+            }
+        }
+    };
+
+    const int64_t NT = N >> 6;                      // full tiles; the < 64 samples behind them: block 0, below
+    const int64_t NG = (NT + 63) >> 6;              // groups of 64 tiles: one tile per lane in the box test
+    const int64_t wg = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+    for (int64_t g = wg; g < NG; g += nw) {
+        const int64_t t = g * 64 + lane;
+        const bool valid = t < NT;
+        unsigned long long todo;                    // tiles of this group that are walked by sample (wave-uniform)
+        if (mode == LLOYD_TILES_FULL) {
+            todo = __ballot(valid);
+        } else {
+            bool pure = false;
+            int j = 0;
+            if (valid) {
+                const v4f b = box[t];
+                const double lox = (double)b.x - m[0], loy = (double)b.y - m[1];
+                const double hix = (double)b.z - m[0], hiy = (double)b.w - m[1];
+                const double corner[D] = {lox, loy};
+                j = label_of(corner);               // the candidate; the test below proves or rejects it for the whole box
+                double cjx = c[0], cjy = c[1], cnj = cn[0];
+#pragma unroll
+                for (int q = 1; q < KMAX; q++)
+                    if (j == q) { cjx = c[q * D]; cjy = c[q * D + 1]; cnj = cn[q]; }
+                const double ax = fmax(fabs(lox), fabs(hix)), ay = fmax(fabs(loy), fabs(hiy));
+                pure = true;
+#pragma unroll
+                for (int q = 0; q < KMAX; q++) {
+                    const double gx = c[q * D] - cjx, gy = c[q * D + 1] - cjy;
+                    // max over the box of D_j - D_q
+                    const double wmax = (cnj - cn[q]) + 2.0 * (fmax(lox * gx, hix * gx) + fmax(loy * gy, hiy * gy));
+                    // every term that enters a sample's D_j, D_q, times 1e-12: >> their f64 rounding (~1e-15 of the same)
+                    const double mag = (fabs(cnj) + fabs(cn[q])) +
+                                       4.0 * (ax * (fabs(c[q * D]) + fabs(cjx)) + ay * (fabs(c[q * D + 1]) + fabs(cjy)));
+                    pure = pure && (q == j || wmax < -1e-12 * mag);
+                }
+                n_tested += 1u;
+                n_pure += pure;
+            }
+            const bool skip = pure && mode == LLOYD_TILES_PRUNED;
+            if (skip) {
+                const v2d s = tsum[t];
+                accumulate(j, s.x, s.y, 64u);
+            }
+            todo = __ballot(valid && !skip);
+        }
+        // walk the remaining tiles: 4 per step (one per 16-lane row), two steps in flight
+        while (todo) {
+            int ta[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (todo) {
+                    ta[i] = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                } else {
+                    ta[i] = -1;
+                }
+            }
+            const int tA = row == 0 ? ta[0] : row == 1 ? ta[1] : row == 2 ? ta[2] : ta[3];
+            const int tB = row == 0 ? ta[4] : row == 1 ? ta[5] : row == 2 ? ta[6] : ta[7];
+            const int64_t tileA = g * 64 + tA, tileB = g * 64 + tB;
+            v4f a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
+            if (tA >= 0) {
+                const v4f *p = reinterpret_cast<const v4f *>(X + tileA * 128 + r16 * 8);
+                a0 = __builtin_nontemporal_load(p);
+                a1 = __builtin_nontemporal_load(p + 1);
+            }
+            if (tB >= 0) {
+                const v4f *p = reinterpret_cast<const v4f *>(X + tileB * 128 + r16 * 8);
+                b0 = __builtin_nontemporal_load(p);
+                b1 = __builtin_nontemporal_load(p + 1);
+            }
+            if (tA >= 0) walk(tileA, a0, a1);
+            if (tB >= 0) walk(tileB, b0, b1);
+        }
+    }
+    // the samples behind the last full tile
+    if (blockIdx.x == 0 && tid < (int)(N - NT * 64)) {
+        const int64_t i = NT * 64 + tid;
+        double x[D] = {(double)X[i * 2] - m[0], (double)X[i * 2 + 1] - m[1]};
+        accumulate(label_of(x), x[0], x[1], 1u);
+        if (first) {
+            sq[0] += x[0] * x[0];
+            sq[1] += x[1] * x[1];
+        }
+    }
+    // ---- record: fold the 256 private columns in a fixed order (as k_lloyd_assign) ----
+    double *rec = partial + (size_t)blockIdx.x * NV;
+    if (tid < NV) rec[tid] = 0.0;
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_tested += __shfl_down(n_tested, off, 64);
+        n_pure += __shfl_down(n_pure, off, 64);
+    }
+    if (lane == 0) { s_tiles[wave][0] = n_tested; s_tiles[wave][1] = n_pure; }
+    __syncthreads();
+    for (int i = wave; i < k * D + k; i += 4) {
+        double a;
+        if (i < k * D) {
+            const double *col = sacc + (size_t)i * 256;
+            a = ((col[lane] + col[lane + 64]) + col[lane + 128]) + col[lane + 192];
+        } else {
+            const unsigned *col = scnt + (size_t)(i - k * D) * 256;
+            a = (double)col[lane] + (double)col[lane + 64] + (double)col[lane + 128] + (double)col[lane + 192];
+        }
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) rec[i < k * D ? i : KMAX * D + (i - k * D)] = a;
+    }
+    if (tid == 0) {
+        rec[KMAX * D + KMAX + 1 + LLOYD_DMAX] = (double)(s_tiles[0][0] + s_tiles[1][0] + s_tiles[2][0] + s_tiles[3][0]);
+        rec[KMAX * D + KMAX + 2 + LLOYD_DMAX] = (double)(s_tiles[0][1] + s_tiles[1][1] + s_tiles[2][1] + s_tiles[3][1]);
+    }
+    if (first) {                                    // uniform: sum (x-mean)^2 per column for sklearn's tol
+        __shared__ double lds_sq[4 * D];
+#pragma unroll
+        for (int f = 0; f < D; f++) {
+            double a = sq[f];
+            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
+            if (lane == 0) lds_sq[wave * D + f] = a;
+        }
+        __syncthreads();
+        if (tid < D) rec[KMAX * D + KMAX + 1 + tid] = ((lds_sq[tid] + lds_sq[D + tid]) + lds_sq[2 * D + tid]) + lds_sq[3 * D + tid];
+    }
+}
+
+bool lloyd_tiles_supported(int dtype, int d, int k) { return dtype == OFC_F32 && d == 2 && k >= 1 && k <= 8; }
+
+template <int KMAX>
+static void launch_tiles_k(const float *X, int64_t N, const LloydState *st, void *box, void *tsum, double *partial,
+                           int nblocks, int build, int first, hipStream_t s)
+{
+    const size_t lds = (size_t)KMAX * (8 * 2 + 4) * 256;
+    if (build)
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, true>), dim3(nblocks), dim3(256), lds, s, X, N, st, (v4f *)box, (v2d *)tsum, partial, first);
+    else
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, false>), dim3(nblocks), dim3(256), lds, s, X, N, st, (v4f *)box, (v2d *)tsum, partial, first);
+}
+
+int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum,
+                       double *partial, int nblocks, int build, int first, hipStream_t s)
+{
+    switch (k) {
+    case 1: launch_tiles_k<1>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 2: launch_tiles_k<2>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 3: launch_tiles_k<3>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 4: launch_tiles_k<4>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 5: launch_tiles_k<5>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 6: launch_tiles_k<6>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 7: launch_tiles_k<7>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 8: launch_tiles_k<8>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    default: set_error("k=%d outside the tile sweep's range (1..8)", k); return OFC_EUNSUPPORTED;
+    }
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+}  // namespace ofc

@@ -1,6 +1,7 @@
 // ofc_api.cpp -- C ABI of libofc.so, part 1: runtime plumbing and the Farneback flow engine.
 // Declared in include/ofc.h (which cites the reference call each entry point replaces).
 #include "color_common.h"
+#include "lloyd_common.h"
 
 #include <cfloat>
 #include <algorithm>
@@ -318,9 +319,13 @@ static int flow_run(ofc_flow *f, const uint8_t *frames_dev, int n_frames, float 
         prevFlow = dst;
         pw = g.w; ph = g.h;
     }
-    if (uv_sum_dev) {       // no epilogue carried them (one iteration per level, staged mode, another winsize): a sweep does
-        set_error("flow sums need the fused winsize-15 engine with at least two iterations per level");
-        return OFC_EUNSUPPORTED;
+    if (uv_sum_dev) {       // no epilogue carried them (one iteration per level, staged mode, another winsize, one of the
+                            // experimental engines): one sweep over the finished field gives the same two sums
+        const int64_t N = (int64_t)npair * W * H;
+        const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(N / 4, 256), 1024));
+        if (f->uv_scratch.bytes < sizeof(double) * 2 * nblocks) OFC_TRY(f->uv_scratch.alloc(sizeof(double) * 2 * nblocks));
+        OFC_TRY(launch_lloyd_colstats(flow_dev, OFC_F32, N, 2, nullptr, 0, f->uv_scratch.as<double>(), nblocks, s));
+        OFC_TRY(launch_reduce_records(f->uv_scratch.as<double>(), nblocks, 2, uv_sum_dev, s));
     }
     return OFC_OK;
 }
@@ -406,10 +411,6 @@ int ofc_flow_calc_frames_dev_stats(ofc_flow_t *f, const uint8_t *frames_dev, int
     OFC_REQUIRE(n_frames >= 2 && n_frames - 1 <= f->max_batch, "n_frames-1 = %d pairs not in [1, max_batch=%d]",
                 n_frames - 1, f->max_batch);
     OFC_TRY(ensure_device(f->device));
-    if (!f->fused || f->prm.iterations < 2) {
-        set_error("flow sums need the fused engine with at least two iterations per level");
-        return OFC_EUNSUPPORTED;
-    }
     return flow_run(f, frames_dev, n_frames, flow_dev, uv_sum_dev);
 }
 

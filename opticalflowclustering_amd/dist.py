@@ -17,13 +17,41 @@ def env_rank_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init_rccl(device, rank, world, broadcast_bytes):
-    """broadcast_bytes(np.uint8[128]) -> np.uint8[128]: rank 0's id delivered to every rank"""
+def _unique_id():
     uid = np.zeros(_lib.UNIQUE_ID_BYTES, np.uint8)
-    if rank == 0:
-        check(load().ofc_dist_unique_id(ptr(uid)))
+    check(load().ofc_dist_unique_id(ptr(uid)))
+    return uid
+
+
+def _rccl_init(device, rank, world, uid):
+    check(load().ofc_dist_init(device, rank, world, ptr(np.ascontiguousarray(uid, np.uint8))))
+
+
+def init_rccl(device, rank, world, broadcast_bytes, vote_min):
+    """Set up the RCCL communicator on every rank, or on none.
+    broadcast_bytes(np.uint8[128]) -> np.uint8[128]: rank 0's array delivered to every rank;
+    vote_min(float) -> float: minimum of the argument over all ranks.
+    Returns None when every rank holds a communicator, else the reason (str) -- the SAME outcome on every rank, and the
+    same sequence of collectives (vote, broadcast, vote) on every rank whatever failed where: a rank that cannot load
+    librccl or create an id still votes, nobody enters the broadcast or ncclCommInitRank unless all can, and a rank whose
+    ncclCommInitRank failed is found by the second vote (the others then drop their communicator)."""
+    uid, err = np.zeros(_lib.UNIQUE_ID_BYTES, np.uint8), None
+    try:
+        uid = _unique_id()              # every rank: proves librccl loads here; rank 0's id is the one that is used
+    except Exception as e:              # noqa: BLE001 -- whatever it is, the other ranks must not be left in a collective
+        err = e
+    if vote_min(0.0 if err is not None else 1.0) < 1.0:
+        return "librccl unusable on %s" % ("this rank: %s" % err if err is not None else "another rank")
     uid = np.ascontiguousarray(broadcast_bytes(uid), np.uint8)
-    check(load().ofc_dist_init(device, rank, world, ptr(uid)))
+    try:
+        _rccl_init(device, rank, world, uid)
+    except Exception as e:              # noqa: BLE001
+        err = e
+    if vote_min(0.0 if err is not None else 1.0) < 1.0:
+        if err is None:
+            finalize()                  # this rank did get a communicator: drop it
+        return "ncclCommInitRank failed on %s" % ("this rank: %s" % err if err is not None else "another rank")
+    return None
 
 
 TRANSPORT = "none"     # what init_from_torch_env set up: "rccl", "gloo-host" (fallback / OFC_DIST_TRANSPORT=gloo) or "none"
@@ -56,20 +84,16 @@ def init_from_torch_env(device):
         td.all_reduce(t, op=ops[op])
         return t.numpy()
 
-    ok, err = 1.0, None
+    def vote_min(v):
+        return float(gloo_allreduce(np.array([v]), "min")[0])
+
     if os.environ.get("OFC_DIST_TRANSPORT") == "gloo":
-        ok = 0.0
+        why = "OFC_DIST_TRANSPORT=gloo"
     else:
-        try:
-            init_rccl(device, rank, world, bcast)
-        except _lib.OfcError as e:
-            ok, err = 0.0, e
-    if gloo_allreduce(np.array([ok]), "min")[0] < 1.0:        # every rank takes the same branch
-        if ok and err is None and os.environ.get("OFC_DIST_TRANSPORT") != "gloo":
-            finalize()                                         # this rank did get a communicator: drop it
+        why = init_rccl(device, rank, world, bcast, vote_min)
+    if why is not None:                                        # every rank took the same branch
         if rank == 0:
-            print("dist: RCCL not used (%s); Lloyd exchange over the gloo host transport" %
-                  (err if err is not None else "OFC_DIST_TRANSPORT=gloo or a failure on another rank"), file=sys.stderr)
+            print("dist: RCCL not used (%s); Lloyd exchange over the gloo host transport" % why, file=sys.stderr)
         init_host(device, rank, world, gloo_allreduce)
         TRANSPORT = "gloo-host"
     else:

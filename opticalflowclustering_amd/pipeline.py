@@ -40,10 +40,6 @@ class ClipPipeline:
         self.n_batches = -(-self.n_pairs // self.batch)
         self.uv_sums = DeviceBuffer(self.n_batches * 16, device)
         self._sums_valid = False
-        p = params or FbParams()
-        import os
-        experimental = any(os.environ.get(v, "0") not in ("", "0") for v in ("OFC_FLOW_FUSE2", "OFC_FLOW_W3", "OFC_FLOW_STAGED"))
-        self._sums_supported = p.winsize == 15 and p.iterations >= 2 and not experimental   # those builds carry no sums
 
     def synth(self, t0=0, seed=0):
         """fill the resident clip with synthetic frames t0 .. t0+n_frames-1"""
@@ -57,7 +53,6 @@ class ClipPipeline:
 
     def run_flow(self, sync=True, stats=True):
         P = self.W * self.H
-        stats = stats and self._sums_supported
         for i, p0 in enumerate(range(0, self.n_pairs, self.batch)):
             n = min(self.batch, self.n_pairs - p0)
             self.engines[i % len(self.engines)].calc_frames_dev(self.frames.ptr + p0 * P, n + 1,

@@ -117,3 +117,62 @@ def test_single_shard_driver_equals_oracle():
         cen, inertia, n_iter = fit_sharded(shard, C0)
         oc, ol, oi, on = O.kmeans_fit(X, C0)
         assert n_iter == on and np.array_equal(shard.labels, ol) and np.abs(cen - oc).max() <= 1e-9
+
+
+def _negotiation_worker(rank, world, port, scenario, q):
+    """one rank of init_from_torch_env with the library calls replaced by stand-ins that fail where `scenario` says"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("OFC_DIST_TRANSPORT", None)
+    import numpy as np
+    from opticalflowclustering_amd import _lib, dist
+    calls = []
+
+    def unique_id():
+        calls.append("unique_id")
+        if scenario == "id_fails_on_%d" % rank:
+            raise _lib.OfcError(_lib.OFC_ECOMM, "librccl.so: cannot open shared object file")
+        return np.full(_lib.UNIQUE_ID_BYTES, 40 + rank, np.uint8)
+
+    def rccl_init(device, r, w, uid):
+        calls.append("rccl_init:%d" % int(uid[0]))            # whose id arrived
+        if scenario == "init_fails_on_%d" % rank:
+            raise _lib.OfcError(_lib.OFC_ECOMM, "ncclCommInitRank failed")
+
+    dist._unique_id, dist._rccl_init = unique_id, rccl_init
+    dist.init_host = lambda device, r, w, allreduce: calls.append("init_host")
+    dist.finalize = lambda: calls.append("finalize")
+    r, w, barrier, allreduce_max = dist.init_from_torch_env(0)
+    barrier()
+    q.put((rank, dist.TRANSPORT, calls, allreduce_max(float(rank))))
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["id_fails_on_0", "id_fails_on_1", "init_fails_on_0", "init_fails_on_1", "all_fine"])
+def test_rccl_setup_failure_on_one_rank_ends_on_the_host_transport_everywhere(scenario):
+    """VERDICT r02 #4 / ADVICE: whichever rank cannot load librccl, create the id or join the communicator, every rank keeps
+    issuing the same gloo collectives and all of them end, within seconds, on the same transport"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, world = _free_port(), 2
+    procs = [ctx.Process(target=_negotiation_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    want = "rccl" if scenario == "all_fine" else "gloo-host"
+    for rank, transport, calls, mx in res:
+        assert transport == want, (rank, transport, calls)
+        assert mx == 1.0                                            # the gloo group is still in step afterwards
+        assert ("init_host" in calls) == (want == "gloo-host")
+        if scenario.startswith("id_fails"):
+            assert not any(c.startswith("rccl_init") for c in calls)     # nobody entered ncclCommInitRank
+        else:
+            assert "rccl_init:40" in calls                          # rank 0's id was the one delivered
+    if scenario.startswith("init_fails"):
+        ok_rank = 1 - int(scenario[-1])
+        assert "finalize" in res[ok_rank][2] and "finalize" not in res[1 - ok_rank][2]

@@ -117,6 +117,8 @@ def test_kmean_grids_pipeline_matches_oracle(tmp_path, monkeypatch):
     KmeanGrids.main(["-d", "OutImgs/clip", "-c", "1", "-f", "x.csv", "--noyolo", "--nocontour", "--path", src])
     rows = list(csv.reader(open(tmp_path / "OutCSV" / "clip.csv")))
     assert rows[0] == [f"cell_{i}" for i in range(350)] and len(rows) == 3
+    # the reference opens `-f` in append mode per cell and writes nothing (KmeanGrids.py:320-330): an empty file is left
+    assert (tmp_path / "x.csv").exists() and (tmp_path / "x.csv").stat().st_size == 0
     for t in (1, 2):
         (vis, _), _ = oracle_vis(v[t - 1], v[t])
         want = []
@@ -603,3 +605,26 @@ def test_flow_epilogue_column_sums_feed_the_fit(W, H, T, batch):
     assert with_stats[2] == without[2]
     assert np.abs(with_stats[0] - without[0]).max() <= 1e-11 and abs(with_stats[1] - without[1]) <= 1e-11 * without[1]
     pipe.close()
+
+
+@pytest.mark.parametrize("variant", ["winsize9", "one_iteration", "staged"])
+def test_flow_column_sums_without_the_epilogue(variant, monkeypatch):
+    """engines whose last level-0 launch carries no epilogue (another winsize, one iteration per level, the staged
+    kernels) still hand back sum(u), sum(v): ofc_flow_calc_frames_dev_stats sweeps the finished field instead of
+    failing after the work was done"""
+    from opticalflowclustering_amd._lib import FbParams
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    prm = FbParams()
+    if variant == "winsize9":
+        prm.winsize = 9
+    elif variant == "one_iteration":
+        prm.iterations = 1
+    else:
+        monkeypatch.setenv("OFC_FLOW_STAGED", "1")
+    pipe = ClipPipeline(320, 200, 4, batch_pairs=3, params=prm, n_engines=1)
+    pipe.synth(t0=1, seed=0)
+    pipe.run_flow(stats=True)
+    want = pipe.flows_host().astype(np.float64).reshape(-1, 2).sum(0)
+    got = pipe.uv_sums.download((1, 2), np.float64)[0]
+    pipe.close()
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())

@@ -86,6 +86,9 @@ CASES = [("t1", 480, 270, lambda W, H: synth.translated_pair(W, H, 1.5, -0.75)),
          ("t3", 640, 360, lambda W, H: synth.translated_pair(W, H, 0.3, 0.2)),
          ("nonrigid", 640, 360, lambda W, H: synth.nonrigid_pair(W, H)[:2]),
          ("noise", 256, 256, lambda W, H: synth.noise_pair(W, H)),
+         # SURVEY 8d cfg1's stress inputs at the size configs[1] names
+         ("nonrigid_1080p", 1920, 1080, lambda W, H: synth.nonrigid_pair(W, H)[:2]),
+         ("noise_1080p", 1920, 1080, lambda W, H: synth.noise_pair(W, H)),
          ("odd", 322, 198, lambda W, H: synth.translated_pair(W, H, -2.2, 1.3)),
          ("odd_both", 321, 199, lambda W, H: synth.translated_pair(W, H, 1.2, 2.1)),
          ("tiny", 17, 16, lambda W, H: synth.translated_pair(W, H, 0.4, -0.3)),
@@ -366,6 +369,10 @@ def test_unrelated_content_outliers_do_not_come_from_the_f32_horizontal_sums(mon
         assert res[mode][0] <= 1e-4
     print("unrelated content: f32 horizontal", res["0"], " f64 horizontal", res["1"])
     assert res["1"][1] > 1e-3 or res["0"][1] <= 1e-3      # if this ever flips, the max-abs bar can be claimed with the f64 build
+    # explicit ceilings: measured 1.05e-2 px / 0.59 % (f32 horizontal sums) and 3.7e-3 px / 0.15 % (f64); a
+    # regression in the near-singular solve path shows up here before it reaches the relative bar
+    assert res["0"][1] <= 3e-2 and res["0"][2] <= 0.015, res["0"]
+    assert res["1"][1] <= 1.5e-2 and res["1"][2] <= 0.006, res["1"]
 
 
 def test_polyexp_f64_horizontal_variant(st, monkeypatch):
