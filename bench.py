@@ -16,7 +16,9 @@ once per iteration.
 Prints ONE JSON line on rank 0 (metric = Mpixels/s of flow+k-means, whole job), including
   roofline     -- the polynomial-expansion kernel (24 B/px algorithmic) timed with HIP events on its own stream over 64
                   distinct resident 1080p images, against the 8 TB/s HBM peak; sub-objects `flow_iter` (the kernel that
-                  dominates a step, 56 B/px) and `pipeline` (whole flow, staged 478 B/px and fused 267 B/px models)
+                  dominates a step, 56 B/px), `lloyd` (the full label-less Lloyd sweep over the clip's 6.2e8 vectors, 8 B/point,
+                  with the pruned tile sweep that replaces it beside it) and `pipeline` (whole flow, staged 478 B/px and
+                  fused 267 B/px models)
   cpu_baseline -- the CPU oracle timed on a bounded sample of the same clip: single thread and all host cores, plus
                   scikit-learn's own KMeans when importable.
 """
@@ -39,6 +41,8 @@ POLYEXP_BYTES_PER_PX = 24  # 4 B read + 5 x 4 B written per pixel 
 FLOW_ITER_BYTES_PER_PX = 56   # SURVEY.md 8d fused iteration: R0 20 + R1 20 (gathered) + flow 8 in + 8 out
 STAGED_BYTES_PER_PX = 478     # whole Farneback per full-res pixel, staged kernels (the model priced against)
 FUSED_BYTES_PER_PX = 267      # M never stored, R computed once per frame
+LLOYD_BYTES_PER_POINT = 8     # label-less sweep of the f32 (u,v) stream (SURVEY.md 8d prices 10: + 1 B label read + 1 B written)
+PMC_JSON = "r03_pmc.json"     # profiles/: HBM traffic per launch from the PMC passes of tools/roofline_pmc.sh
 MAX_BATCH = 32
 
 
@@ -139,6 +143,22 @@ def main():
                        "parallelism": "frames sharded x%d, all-reduce of k*(d+1)+1 f64 per Lloyd iteration, transport %s"
                                       % (world, {"rccl": "RCCL", "gloo-host": "gloo (host fallback)", "none": "none (one rank)"}[dist.TRANSPORT])},
         }
+    def guarded(slot, fn):
+        """an informational leg must never cost the headline line that was already measured"""
+        try:
+            return fn()
+        except Exception as e:            # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return {"error": "%s in %s: %s" % (e.__class__.__name__, slot, e)}
+
+    if rank == 0:
+        from opticalflowclustering_amd.cluster import prune_stats
+        ps = prune_stats(device)
+        out["config"]["lloyd_skip_fraction"] = ps["skip_fraction"]
+        out["config"]["lloyd_sweeps"] = {"tile_sweeps": ps["tile_sweeps"], "pruned": ps["pruned_sweeps"], "probes": ps["probe_sweeps"],
+                                         "what": "label-less Lloyd iterations over 64-sample tiles; a pruned sweep reads only the "
+                                                 "tiles whose (u,v) box is not inside one Voronoi cell (skip fraction = tiles not read)"}
     if not args.no_extras:
         # ---- informational legs, outside the timed region ----
         # (1) the flow alone over the same resident clip (the configs[1] shape: many distinct 1080p pairs per launch sequence)
@@ -150,51 +170,107 @@ def main():
         dt_flow = allreduce_max(time.perf_counter() - tf) / 2
         if rank == 0:
             out["config"]["flow_only_mpx_s"] = n_pairs_total * W * H / 1e6 / dt_flow
-        # (2) the labelled, host-driven fit (sharded.fit_sharded over a DeviceShard: the form that reads and writes labels
-        # every iteration) over the resident flows must land where the label-less in-library fit did
         if world == 1 and not force_dist:
-            out["config"]["labelled_fit_check"] = labelled_fit_check(pipe, centers, n_iter, device)
+            # (2) the pruned fit must be the unpruned one (same n_iter, same labels, centres <= 1e-9), and the labelled,
+            # host-driven fit (sharded.fit_sharded over a DeviceShard: reads and writes labels every iteration) over the
+            # resident flows must land where the label-less in-library fit did
+            out["config"]["pruned_fit_check"] = guarded("pruned_fit_check", lambda: pruned_fit_check(pipe, centers, n_iter, inertia))
+            out["config"]["labelled_fit_check"] = guarded("labelled_fit_check", lambda: labelled_fit_check(pipe, centers, n_iter, device))
+            lloyd_roof = guarded("roofline.lloyd", lambda: lloyd_roofline(pipe, centers, device))
     pipe.close()
     if rank == 0 and world == 1 and not args.no_extras and args.frames == CLIP_FRAMES:
         # (3) what one rank of an 8-GPU run does per step, alone on this GPU (no collective: RCCL refuses two ranks on one
         # device) -- the numbers the >= 6x scaling target is priced on
-        out["config"].update(shard_step_ms(device, args.engines, centers, int(n_iter)))
+        out["config"].update(guarded("shard_step_ms", lambda: shard_step_ms(device, args.engines, centers, int(n_iter))))
     if rank == 0:
-        # ---- roofline leg: the polyexp kernel, HIP events on its own stream, 64 distinct 1080p images ----
-        n_img, iters = 64, 20
-        ms = stages.bench_polyexp(W, H, n_img, iters, 0, device)
-        achieved = POLYEXP_BYTES_PER_PX * W * H * n_img / (ms * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "k_polyexp", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_polyexp"),
-                           "launch_ms": ms, "images_per_launch": n_img,
-                           "algorithmic_bytes_per_launch": POLYEXP_BYTES_PER_PX * W * H * n_img}
-        # the kernel that dominates a step (60 % of it): one level-0 Farneback iteration over 32 resident pairs
-        n_pairs_l = 32
-        ms_it = stages.bench_flow_iters(W, H, n_pairs_l, 10, 0, device) / 2
-        alg = FLOW_ITER_BYTES_PER_PX * W * H * n_pairs_l
-        out["roofline"]["flow_iter"] = {"kernel": "k_flow_iter<7,0>", "bound": "hbm",
-                                        "achieved": alg / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": alg / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": pmc_traffic("k_flow_iter"), "launch_ms": ms_it,
-                                        "pairs_per_launch": n_pairs_l, "algorithmic_bytes_per_launch": alg}
-        if "flow_only_mpx_s" in out["config"]:
-            f = out["config"]["flow_only_mpx_s"] * 1e6
-            out["roofline"]["pipeline"] = {
-                "what": "whole Farneback flow (all levels, all kernels) over the resident clip, per full-res pixel",
-                "model": "staged (SURVEY.md 8d: 478 B/px, M stored, every kernel separate) is the one priced; the fused "
-                         "model (267 B/px: M never stored, R computed once per frame) is what the engine's kernels move",
-                "staged_bytes_per_px": STAGED_BYTES_PER_PX, "fused_bytes_per_px": FUSED_BYTES_PER_PX,
-                "achieved_staged": f * STAGED_BYTES_PER_PX / 1e9, "frac_staged": f * STAGED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
-                "achieved_fused": f * FUSED_BYTES_PER_PX / 1e9, "frac_fused": f * FUSED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        out["roofline"] = guarded("roofline", lambda: kernel_rooflines(device, out["config"].get("flow_only_mpx_s")))
+        if world == 1 and not force_dist and not args.no_extras and isinstance(out["roofline"], dict):
+            out["roofline"]["lloyd"] = lloyd_roof
         # ---- CPU baseline: the oracle on a bounded sample of the same clip ----
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(device)
+            out["cpu_baseline"] = guarded("cpu_baseline", lambda: cpu_baseline(device))
     if world > 1 or force_dist:
         barrier()            # rank 0 ran the roofline legs meanwhile: tear the communicator down together
         dist.finalize()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def kernel_rooflines(device, flow_only_mpx_s):
+    """roofline leg: the polyexp kernel, HIP events on its own stream, 64 distinct 1080p images; then the flow iteration"""
+    from opticalflowclustering_amd import stages
+    n_img, iters = 64, 20
+    ms = stages.bench_polyexp(W, H, n_img, iters, 0, device)
+    achieved = POLYEXP_BYTES_PER_PX * W * H * n_img / (ms * 1e-3) / 1e9
+    roof = {"kernel": "k_polyexp", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_polyexp"),
+            "launch_ms": ms, "images_per_launch": n_img,
+            "algorithmic_bytes_per_launch": POLYEXP_BYTES_PER_PX * W * H * n_img}
+    # the kernel that dominates a step: one level-0 Farneback iteration over 32 resident pairs
+    n_pairs_l = 32
+    ms_it = stages.bench_flow_iters(W, H, n_pairs_l, 10, 0, device) / 2
+    alg = FLOW_ITER_BYTES_PER_PX * W * H * n_pairs_l
+    roof["flow_iter"] = {"kernel": "k_flow_iter<7,0>", "bound": "hbm",
+                         "achieved": alg / (ms_it * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("k_flow_iter"), "launch_ms": ms_it,
+                         "pairs_per_launch": n_pairs_l, "algorithmic_bytes_per_launch": alg}
+    if flow_only_mpx_s:
+        f = flow_only_mpx_s * 1e6
+        roof["pipeline"] = {
+            "what": "whole Farneback flow (all levels, all kernels) over the resident clip, per full-res pixel",
+            "model": "staged (SURVEY.md 8d: 478 B/px, M stored, every kernel separate) is the one priced; the fused "
+                     "model (267 B/px: M never stored, R computed once per frame) is what the engine's kernels move",
+            "staged_bytes_per_px": STAGED_BYTES_PER_PX, "fused_bytes_per_px": FUSED_BYTES_PER_PX,
+            "achieved_staged": f * STAGED_BYTES_PER_PX / 1e9,
+            "model_ratio_staged": f * STAGED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
+            "model_ratio_staged_note": "NOT a fraction of peak that was moved: the staged model prices traffic (M, per-kernel "
+                                       "R re-reads) that the fused engine never generates, so this ratio may exceed 1",
+            "achieved_fused": f * FUSED_BYTES_PER_PX / 1e9, "frac_fused": f * FUSED_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    return roof
+
+
+def pruned_fit_check(pipe, centers, n_iter, inertia):
+    """the fit bench.py timed (tile sweeps, pruned) against the same fit with every sweep full (OFC_LLOYD_PRUNE=0) over
+    the resident 6.2e8 vectors: n_iter equal, labels bit-equal, centres <= 1e-9 (VERDICT r02 #1's done-when)"""
+    lab_pruned = pipe.labels_host()
+    old = os.environ.get("OFC_LLOYD_PRUNE")
+    os.environ["OFC_LLOYD_PRUNE"] = "0"
+    try:
+        c0, in0, it0 = pipe.run_kmeans(INIT, max_iter=300, tol=1e-4)
+    finally:
+        if old is None:
+            os.environ.pop("OFC_LLOYD_PRUNE", None)
+        else:
+            os.environ["OFC_LLOYD_PRUNE"] = old
+    same_labels = bool(np.array_equal(lab_pruned, pipe.labels_host()))
+    dc = float(np.abs(c0 - centers).max())
+    return {"ok": bool(int(it0) == int(n_iter) and same_labels and dc <= 1e-9), "n_iter": [int(n_iter), int(it0)],
+            "labels_equal": same_labels, "max_abs_centre_diff": dc, "inertia_rel_diff": float(abs(in0 - inertia) / in0)}
+
+
+def lloyd_roofline(pipe, centers, device):
+    """the Lloyd sweeps over the clip's resident vectors, HIP events on the Lloyd stream, centres fixed at the converged ones"""
+    from opticalflowclustering_amd import stages
+    N = pipe.n_pairs * W * H
+    from opticalflowclustering_amd import _lib
+    colsum = np.zeros(2)
+    _lib.check(_lib.load().ofc_lloyd_colstats_dev(device, pipe.flows.ptr, _lib.F32, N, 2, None, 0, _lib.ptr(colsum)))
+    mean = colsum / N
+    ms = {name: stages.bench_lloyd_sweep(pipe.flows.ptr, N, centers, mean, what, 10, device)
+          for name, what in (("full", 0), ("pruned", 1), ("build", 2), ("final", 3))}
+    alg = LLOYD_BYTES_PER_POINT * N
+    return {"kernel": "k_lloyd_assign<2,5,float,3>", "bound": "hbm", "achieved": alg / (ms["full"] * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("k_lloyd_assign"), "launch_ms": ms["full"], "points_per_launch": N,
+            "algorithmic_bytes_per_launch": alg,
+            "frac_at_10_bytes_per_point": 10 * N / (ms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "the full label-less sweep (8 B/point; SURVEY.md 8d's 10 B/point form reads and writes a label byte as "
+                    "well).  In the default fit only the final E-step still reads every sample: iteration 0 is `build_ms` "
+                    "(full read + 32 B of tile metadata written per 64 samples), iterations 1.. are `pruned_ms` each",
+            "pruned_ms": ms["pruned"], "build_ms": ms["build"], "final_estep_ms": ms["final"],
+            "pruned_traffic": pmc_traffic("k_lloyd_tiles_pruned")}
 
 
 def labelled_fit_check(pipe, centers, n_iter, device):
@@ -241,19 +317,19 @@ def shard_step_ms(device, engines, global_centers, global_iters, steps=10):
 def source_sha16():
     """fingerprint of the kernel sources a recorded PMC pass belongs to"""
     h = hashlib.sha256()
-    for name in ("flow_kernels.hip",):
+    for name in ("flow_kernels.hip", "lloyd_kernels.hip", "lloyd_tiles.hip"):
         with open(os.path.join(ROOT, "opticalflowclustering_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, the
     gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read from inside the benchmark process, so this is the
     value recorded for the same launch configuration -- and only while the kernel source is the one the passes were
-    collected on (sha of flow_kernels.hip recorded beside them); otherwise null."""
+    collected on (sha of the kernel sources recorded beside them); otherwise null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_JSON)) as f:
             rec = json.load(f)
         if rec.get("source_sha16") != source_sha16():
             return None
@@ -277,7 +353,10 @@ def cpu_baseline(device, single_pairs=4, multi_pairs=32):
     pipe.synth(t0=0, seed=0)
     frames = pipe.frames.download((multi_pairs + 1, H, W), np.uint8)
     pipe.close()
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    quota = cpu_quota()
+    # threads = the CPUs this process can really use: its affinity mask, capped by the cgroup's CPU quota when there is one
+    # (a GPU box grants a 16-CPU share of its 256 cores: 64 threads on 16 CPUs only oversubscribe)
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(np.ceil(quota)) if quota else 64))
     N = O.native()                                      # -O3 -march=native build of the same C files, made here
     # ---- (a) one thread ----
     t0 = time.perf_counter()
@@ -290,6 +369,7 @@ def cpu_baseline(device, single_pairs=4, multi_pairs=32):
               "sample": "first %d pairs: flow %.2f s + Lloyd k=5 %d iterations %.2f s" % (single_pairs, t_flow1, it1, t_km1)}
     # ---- (b) all cores ----
     with ThreadPoolExecutor(cores) as pool:
+        cpu0 = time.process_time()
         t0 = time.perf_counter()
         flows = np.stack(list(pool.map(lambda t: N.farneback(frames[t], frames[t + 1]), range(multi_pairs))))
         t_flow = time.perf_counter() - t0
@@ -298,7 +378,9 @@ def cpu_baseline(device, single_pairs=4, multi_pairs=32):
         t0 = time.perf_counter()
         _, _, it = fit_sharded(shard, INIT, max_iter=300, tol=1e-4)
         t_km = time.perf_counter() - t0
+        cpu_used = time.process_time() - cpu0
     allc = {"value": multi_pairs * P / 1e6 / (t_flow + t_km), "unit": "Mpixels/s", "cores": cores,
+            "cpu_seconds_per_wall_second": cpu_used / (t_flow + t_km),
             "sample": "first %d pairs: flow %.2f s + Lloyd k=5 %d iterations %.2f s, %d threads" % (multi_pairs, t_flow, it, t_km, cores)}
     # ---- (c) the reference's own Lloyd ----
     try:
@@ -319,7 +401,29 @@ def cpu_baseline(device, single_pairs=4, multi_pairs=32):
         sk = "unavailable on this box (%s)" % e.__class__.__name__
     return {"value": allc["value"], "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": allc["sample"] + "; oracle/*.c built -O3 -march=native on this host",
-            "single_thread": single, "all_cores": allc, "sklearn_kmeans": sk, "host_cores_available": os.cpu_count()}
+            "single_thread": single, "all_cores": allc, "sklearn_kmeans": sk, "host_cores_available": os.cpu_count(),
+            "cpu_quota_cores": quota,
+            "cores_note": "`cores` = threads started (min(affinity, cgroup quota; 64 without a quota)); `cpu_quota_cores` = CPU time per wall second this "
+                          "process's cgroup grants (cpu.max; null = no limit readable); `cpu_seconds_per_wall_second` in "
+                          "all_cores = what the threaded leg actually got"}
+
+
+def cpu_quota():
+    """CPU share of this process's cgroup in cores (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unreadable"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
 
 
 class ThreadedOracleShard:

@@ -199,6 +199,12 @@ int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N
  * tiles tested by the pruned sweeps, tiles they skipped, probe sweeps, reserved].  Environment: OFC_LLOYD_PRUNE=0 switches
  * the tile sweeps off, 2 enables them for any N, 3 also forces every one of them to run pruned. */
 int ofc_lloyd_prune_stats(int device, double *out6);
+/* Measurement hook (bench.py's roofline.lloyd): average duration, by HIP events on the Lloyd stream, of `iters` launches of
+ * one sweep over the resident float32 (u,v) stream X_dev[N][2] with fixed centres (k x 2, uncentred) and column mean.
+ * what = 0: the full label-less sweep (k_lloyd_assign mode 3, 8 B/sample); 1: the pruned tile sweep (metadata built first,
+ * untimed); 2: the sweep that builds the tile metadata (iteration 0); 3: the final E-step (labels + inertia). */
+int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, const double *centers, const double *mean,
+                          int what, int iters, float *ms_per_launch);
 /* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same
  * kernels, one pass per call, records returned to the host so that ANY collective (RCCL, or
  * torch.distributed/gloo across nodes) can combine the shards.  X_dev is this rank's shard. ---- */

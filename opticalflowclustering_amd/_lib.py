@@ -77,6 +77,7 @@ _PROTOS = {
     "ofc_kmeans_fit_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, C.POINTER(_d), _ip], _i),
     "ofc_kmeans_fit_dev_stats": ([_i, _vp, _i, _i64, _i, _i, _vp, _i, _d, _vp, _vp, _vp, C.POINTER(_d), _ip], _i),
     "ofc_lloyd_prune_stats": ([_i, _vp], _i),
+    "ofc_bench_lloyd_sweep": ([_i, _vp, _i64, _i, _vp, _vp, _i, _i, C.POINTER(_f)], _i),
     "ofc_lloyd_colstats_dev": ([_i, _vp, _i, _i64, _i, _vp, _i, _vp], _i),
     "ofc_lloyd_step_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _vp], _i),
     "ofc_lloyd_inertia_dev": ([_i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, C.POINTER(_d)], _i),

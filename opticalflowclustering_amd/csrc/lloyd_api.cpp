@@ -351,6 +351,63 @@ int ofc_kmeans_fit_dev(int device, const void *X_dev, int dtype, int64_t N, int 
 }
 
 /* see include/ofc.h */
+int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, const double *centers, const double *mean,
+                          int what, int iters, float *ms_per_launch)
+{
+    OFC_REQUIRE(X_dev && centers && mean && ms_per_launch && iters >= 1 && N >= 64, "bad arguments");
+    OFC_REQUIRE(what >= 0 && what <= 3, "what = %d outside 0..3", what);
+    if (!lloyd_tiles_supported(OFC_F32, 2, k)) { set_error("k=%d outside 1..8", k); return OFC_EUNSUPPORTED; }
+    OFC_TRY(ensure_device(device));
+    LloydScratch &sc = scratch_for(device);
+    std::lock_guard<std::mutex> lock(sc.mu);
+    OFC_TRY(sc.init());
+    hipStream_t s = sc.stream;
+    const int nblocks = lloyd_grid(N);
+    const size_t need = (size_t)(N >> 6) * 16;
+    if (sc.tile_box.bytes < need) {
+        OFC_TRY(sc.tile_box.alloc(need));
+        OFC_TRY(sc.tile_sum.alloc(need));
+    }
+    if (sc.labels.bytes < (size_t)N) OFC_TRY(sc.labels.alloc((size_t)N));
+    LloydState *st = sc.state.as<LloydState>();
+    OFC_HIP(hipMemsetAsync(st, 0, sizeof(LloydState), s));
+    double c0[LLOYD_KMAX * LLOYD_DMAX];
+    for (int j = 0; j < k * 2; j++) c0[j] = centers[j] - mean[j % 2];
+    OFC_HIP(hipMemcpyAsync(st->mean, mean, sizeof(double) * 2, hipMemcpyHostToDevice, s));
+    OFC_HIP(hipMemcpyAsync(st->centers, c0, sizeof(double) * k * 2, hipMemcpyHostToDevice, s));
+    OFC_TRY(launch_lloyd_set_centers(st, k, 2, s, LLOYD_PRUNE_ALWAYS));
+    double *partial = sc.partial.as<double>();
+    const float *X = X_dev;
+    auto launch = [&]() -> int {
+        switch (what) {
+        case 0: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 3, 0, s);
+        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 0, 0, s);
+        case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 1, 1, s);
+        default: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 2, 0, s);
+        }
+    };
+    if (what == 1) {      // the pruned sweep needs the tile metadata and its mode flag
+        OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 1, 1, s));
+        const int mode = LLOYD_TILES_PRUNED;
+        OFC_HIP(hipMemcpyAsync(&st->prune_mode, &mode, sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    hipEvent_t e0, e1;
+    OFC_HIP(hipEventCreate(&e0));
+    OFC_HIP(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) OFC_TRY(launch());
+    OFC_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; i++) OFC_TRY(launch());
+    OFC_HIP(hipEventRecord(e1, s));
+    OFC_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    OFC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return OFC_OK;
+}
+
+/* see include/ofc.h */
 int ofc_lloyd_prune_stats(int device, double *out6)
 {
     OFC_REQUIRE(out6, "null pointer");

@@ -79,3 +79,13 @@ def bench_polyexp(W, H, n_images, iters, rows_per_block=0, device=0):
     ms = C.c_float()
     check(load().ofc_bench_polyexp(device, W, H, n_images, iters, rows_per_block, C.byref(ms)))
     return ms.value
+
+
+def bench_lloyd_sweep(X_ptr, N, centers, mean, what, iters=10, device=0):
+    """ms per launch of one Lloyd sweep over a resident (u,v) stream (ofc_bench_lloyd_sweep): what 0 full label-less sweep,
+    1 pruned tile sweep, 2 metadata-building sweep, 3 final E-step"""
+    cen = np.ascontiguousarray(centers, np.float64)
+    mean = np.ascontiguousarray(mean, np.float64)
+    ms = C.c_float()
+    check(load().ofc_bench_lloyd_sweep(device, C.c_void_p(X_ptr), N, len(cen), ptr(cen), ptr(mean), what, iters, C.byref(ms)))
+    return ms.value
