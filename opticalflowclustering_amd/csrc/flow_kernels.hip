@@ -221,32 +221,53 @@ __global__ __launch_bounds__(256) void k_level_dec(const uint8_t *__restrict__ s
     float *out = dst + (size_t)blockIdx.z * w * h;
     const int yfirst = S * oy0 + S / 2 - 1 - R;           // global row of tile row 0 (before reflection)
 
-    for (int it = tid; it < ROWS * TXO; it += 256) {
-        const int ly = it / TXO, j = it - ly * TXO;
-        const int ox = ox0 + j;
-        if (ox >= w) continue;
-        const uint8_t *row = img + (size_t)reflect101(yfirst + ly, H0) * W0;
+    // thread <-> (output column j, row group rg): the thread's RPG input rows are requested back to back before any of
+    // them is used (the first version walked "items" one after the other: five dependent memory round trips per work-group
+    // on the 1/4 level, which made this trivial kernel 8 % of the flow time)
+    constexpr int NG = 256 / TXO, RPG = (ROWS + NG - 1) / NG;
+    const int j = tid % TXO, rg = tid / TXO;
+    const int ox = ox0 + j;
+    if (ox < w) {
         const int xs = S * ox + XOFF;                     // first byte of the window
-        float b[NB];
-        if (xs - AL >= 0 && xs - AL + 4 * NW <= W0) {
-            const uint32_t *rw = reinterpret_cast<const uint32_t *>(row + (xs - AL));
-            uint32_t wd[NW];
+        const bool fast = xs - AL >= 0 && xs - AL + 4 * NW <= W0;
+        auto refl = [](int p, int len) { return p < 0 ? -p : (p >= len ? 2 * (len - 1) - p : p); };   // |overshoot| < len (launcher)
+        auto rowpass = [&](int i, const float (&b)[NB]) {
+            const int ly = rg + NG * i;
+            float a0 = p.kern[0] * b[0], a1 = p.kern[0] * b[1];
 #pragma unroll
-            for (int q = 0; q < NW; q++) wd[q] = rw[q];
+            for (int q = 1; q <= 2 * R; q++) {
+                a0 += p.kern[q] * b[q];
+                a1 += p.kern[q] * b[q + 1];
+            }
+            if (ly < ROWS) *reinterpret_cast<float2 *>(&hrow[ly][j][0]) = make_float2(a0, a1);
+        };
+        if (fast) {
+            uint32_t wd[RPG][NW];
 #pragma unroll
-            for (int q = 0; q < NB; q++) b[q] = ubyte_of(wd[(AL + q) >> 2], (AL + q) & 3);
+            for (int i = 0; i < RPG; i++) {
+                const int ly = min(rg + NG * i, ROWS - 1);
+                const uint32_t *rw = reinterpret_cast<const uint32_t *>(img + (size_t)refl(yfirst + ly, H0) * W0 + (xs - AL));
+#pragma unroll
+                for (int q = 0; q < NW; q++) wd[i][q] = rw[q];
+            }
+#pragma unroll
+            for (int i = 0; i < RPG; i++) {
+                float b[NB];
+#pragma unroll
+                for (int q = 0; q < NB; q++) b[q] = ubyte_of(wd[i][(AL + q) >> 2], (AL + q) & 3);
+                rowpass(i, b);
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < NB; q++) b[q] = (float)row[reflect101(xs + q, W0)];
-        }
-        float a0 = p.kern[0] * b[0], a1 = p.kern[0] * b[1];
+            for (int i = 0; i < RPG; i++) {
+                const int ly = min(rg + NG * i, ROWS - 1);
+                const uint8_t *row = img + (size_t)refl(yfirst + ly, H0) * W0;
+                float b[NB];
 #pragma unroll
-        for (int q = 1; q <= 2 * R; q++) {
-            a0 += p.kern[q] * b[q];
-            a1 += p.kern[q] * b[q + 1];
+                for (int q = 0; q < NB; q++) b[q] = (float)row[reflect101(xs + q, W0)];
+                rowpass(i, b);
+            }
         }
-        hrow[ly][j][0] = a0;
-        hrow[ly][j][1] = a1;
     }
     __syncthreads();
     for (int it = tid; it < TYO * TXO; it += 256) {
@@ -290,7 +311,7 @@ int launch_level_image(const uint8_t *src, float *dst, int nimg, int W0, int H0,
         return OFC_OK;
     }
 #define OFC_DEC(S_, R_, TX_, TY_)                                                                          \
-    if (aligned && g.w * S_ == W0 && g.h * S_ == H0 && a.r == R_) {                                        \
+    if (aligned && g.w * S_ == W0 && g.h * S_ == H0 && a.r == R_ && H0 > 2 * R_ + S_ && W0 > 2 * R_ + 8) {                                        \
         hipLaunchKernelGGL((k_level_dec<S_, R_, TX_, TY_>), dim3(cdiv(g.w, TX_), cdiv(g.h, TY_), nimg),    \
                            dim3(256), 0, s, src, dst, W0, H0, g.w, g.h, a);                                \
         OFC_HIP(hipGetLastError());                                                                        \

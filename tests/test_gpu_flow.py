@@ -21,7 +21,7 @@ def rel(a, b):
     return np.linalg.norm((a - b).ravel().astype(np.float64)) / max(np.linalg.norm(b.ravel().astype(np.float64)), 1e-30)
 
 
-@pytest.mark.parametrize("W,H", [(256, 256), (480, 270), (322, 198), (1280, 720)])
+@pytest.mark.parametrize("W,H", [(256, 256), (480, 270), (322, 198), (1280, 720), (1920, 1080), (64, 40)])
 def test_level_image_bit_exact(st, W, H):
     rng = np.random.default_rng(W + H)
     gray = rng.integers(0, 256, (H, W), dtype=np.uint8)

@@ -22,9 +22,21 @@ __device__ __forceinline__ void disp(int x, int y, int &x1, int &y1)
 }
 
 // block = 256 threads <-> 256 columns, marches down ROWS rows (4 rows of loads in flight, as k_flow_iter)
+// work > 0: after the loads of a 4-row step every lane runs `work` dependent FMAs per fetched value pair and the work-group
+// crosses two barriers, as a step of k_flow_iter does (matrix arithmetic, exchange, horizontal pass): with the dynamic LDS
+// request limiting a CU to two work-groups this reproduces the kernel's burst / compute alternation at 2 waves per SIMD
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void k_gather(const float *__restrict__ R, const float *__restrict__ RB, float *out, int rows)
+__global__ __launch_bounds__(256) void k_gather(const float *__restrict__ R, const float *__restrict__ RB, float *out, int rows, int work, int stagger, int sh)
 {
+    extern __shared__ float dyn_lds[];
+    // stagger > 0: half of the work-groups (bit `sh` of the linear id) start `stagger` x 640 clocks late, so that the chip's
+    // work-groups do not all load and all compute at the same time (the convoy that forms when every work-group starts
+    // together and HBM completes everybody's step at about the same time)
+    {
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (stagger && ((lin >> sh) & 1))
+            for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(10);
+    }
     const int x = min(blockIdx.x * 242 + threadIdx.x, W - 1);
     const int y0 = blockIdx.y * rows;
     const size_t plane = (size_t)W * H;
@@ -79,6 +91,17 @@ __global__ __launch_bounds__(256) void k_gather(const float *__restrict__ R, con
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int i = 0; i < 25; i++) acc += v[r][i];
+        if (work) {
+            __syncthreads();
+            float a0 = acc, a1 = acc + 1.f, a2 = acc + 2.f, a3 = acc + 3.f;
+            for (int i = 0; i < work; i++) {
+                a0 = fmaf(a0, 1.0001f, 0.5f); a1 = fmaf(a1, 1.0001f, 0.5f);
+                a2 = fmaf(a2, 1.0001f, 0.5f); a3 = fmaf(a3, 1.0001f, 0.5f);
+            }
+            acc = (a0 + a1) + (a2 + a3);
+            if (acc == 777.f) dyn_lds[threadIdx.x] = acc;
+            __syncthreads();
+        }
     }
     if (acc == 12345.678f) out[0] = acc;
 }
@@ -93,8 +116,11 @@ template <class F> float timeit(F f, int iters)
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int lds = argc > 1 ? atoi(argv[1]) : 0;        // dynamic LDS bytes per work-group (occupancy limiter)
+    const int work = argc > 2 ? atoi(argv[2]) : 0;       // dependent FMA quadruples per 4-row step
+    const int stagger = argc > 3 ? atoi(argv[3]) : 0, sh = argc > 4 ? atoi(argv[4]) : 0;
     const int NP = 32;                       // pairs; NP + 1 frames of R
     const size_t plane = (size_t)W * H;
     float *R, *RB, *out;
@@ -105,12 +131,18 @@ int main()
     CK(hipMemset(RB, 0, sizeof(float) * plane * (NP + 1)));
     const int rows = 272;
     dim3 grid((W + 241) / 242, (H + rows - 1) / rows, NP);
+    if (lds > 48 * 1024) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    printf("dynamic LDS %d B per work-group, %d FMA quadruples per step, stagger %d x 640 clk on bit %d\n", lds, work, stagger, sh);
     float ms;
-    ms = timeit([&] { hipLaunchKernelGGL(k_gather<0>, grid, dim3(256), 0, 0, R, RB, out, rows); }, 10);
+    ms = timeit([&] { hipLaunchKernelGGL(k_gather<0>, grid, dim3(256), lds, 0, R, RB, out, rows, work, stagger, sh); }, 10);
     printf("A interleaved [px][5], unaligned x4   %.3f ms  (%.0f GB/s of 40 B/px unique)\n", ms, 40.0 * plane * NP / ms / 1e6);
-    ms = timeit([&] { hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), 0, 0, R, RB, out, rows); }, 10);
+    ms = timeit([&] { hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), lds, 0, R, RB, out, rows, work, stagger, sh); }, 10);
     printf("B split float4 + float, aligned x4    %.3f ms  (%.0f GB/s of 40 B/px unique)\n", ms, 40.0 * plane * NP / ms / 1e6);
-    ms = timeit([&] { hipLaunchKernelGGL(k_gather<2>, grid, dim3(256), 0, 0, R, RB, out, rows); }, 10);
+    ms = timeit([&] { hipLaunchKernelGGL(k_gather<2>, grid, dim3(256), lds, 0, R, RB, out, rows, work, stagger, sh); }, 10);
     printf("C padded [px][8], aligned x4          %.3f ms  (%.0f GB/s of 64 B/px unique)\n", ms, 64.0 * plane * NP / ms / 1e6);
     return 0;
 }
