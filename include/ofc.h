@@ -195,14 +195,16 @@ int ofc_kmeans_fit_dev_stats(int device, const void *X_dev, int dtype, int64_t N
  * _k_means_lloyd.pyx:23-218, reads every sample in every iteration).  For a float32 d=2 stream (the per-pixel (u,v) vectors
  * of computeOpticalFlow.py:99-101's field) of >= 2^20 samples and k <= 8 the label-less iterations run over 64-sample
  * tiles; a tile whose (u,v) bounding box lies inside one Voronoi cell of the current centres contributes its cached sum
- * without being read (exact: same labels, same n_iter, centres equal to rounding).  out6 = [tile sweeps, of them pruned,
- * tiles tested by the pruned sweeps, tiles they skipped, probe sweeps, reserved].  Environment: OFC_LLOYD_PRUNE=0 switches
+ * without being read, in the iterations and in the final E-step (exact: same labels, same n_iter, centres and inertia equal
+ * to rounding).  out6 = [tile sweeps, of them pruned,
+ * tiles tested by the pruned sweeps, tiles they skipped, probe sweeps, 1 if the final E-step ran pruned].  Environment: OFC_LLOYD_PRUNE=0 switches
  * the tile sweeps off, 2 enables them for any N, 3 also forces every one of them to run pruned. */
 int ofc_lloyd_prune_stats(int device, double *out6);
 /* Measurement hook (bench.py's roofline.lloyd): average duration, by HIP events on the Lloyd stream, of `iters` launches of
  * one sweep over the resident float32 (u,v) stream X_dev[N][2] with fixed centres (k x 2, uncentred) and column mean.
  * what = 0: the full label-less sweep (k_lloyd_assign mode 3, 8 B/sample); 1: the pruned tile sweep (metadata built first,
- * untimed); 2: the sweep that builds the tile metadata (iteration 0); 3: the final E-step (labels + inertia). */
+ * untimed); 2: the sweep that builds the tile metadata (iteration 0); 3: the full final E-step (labels + inertia, every sample
+ * read); 4: the pruned final E-step (tiles inside one cell labelled without being read). */
 int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, const double *centers, const double *mean,
                           int what, int iters, float *ms_per_launch);
 /* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same

@@ -167,5 +167,5 @@ def prune_stats(device=0):
     pruned, and the share of tiles the pruned sweeps did not have to read"""
     out = np.zeros(6, np.float64)
     check(load().ofc_lloyd_prune_stats(device, ptr(out)))
-    return {"tile_sweeps": int(out[0]), "pruned_sweeps": int(out[1]), "probe_sweeps": int(out[4]),
+    return {"tile_sweeps": int(out[0]), "pruned_sweeps": int(out[1]), "probe_sweeps": int(out[4]), "final_pruned": bool(out[5]),
             "skip_fraction": float(out[3] / out[2]) if out[2] > 0 else 0.0}

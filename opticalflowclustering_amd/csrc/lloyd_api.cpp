@@ -23,7 +23,7 @@ static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC
 // pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
     DevBuf state, partial, tot, tot_local, excl, far, labels;
-    DevBuf tile_box, tile_sum;           // lloyd_tiles.hip: 16 + 16 B per 64-sample tile, rebuilt by every fit's iteration 0
+    DevBuf tile_box, tile_sum, tile_sq;  // lloyd_tiles.hip: 16 + 16 + 8 B per 64-sample tile, rebuilt by every fit's iteration 0
     double prune_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last fit, see ofc_lloyd_prune_stats
     LloydStatus *status = nullptr;       // pinned, device-visible; one slot per iteration of a window
     LloydStatus *status_dev = nullptr;
@@ -212,6 +212,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
         if (sc.tile_box.bytes < need) {
             OFC_TRY(sc.tile_box.alloc(need));
             OFC_TRY(sc.tile_sum.alloc(need));
+            OFC_TRY(sc.tile_sq.alloc(need / 2));
         }
     }
     for (double &v : sc.prune_stats) v = 0;
@@ -231,6 +232,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     // finds st->halt set and does nothing.  One host round trip per window instead of one per iteration (18 us each -- a tenth of an
     // iteration on a 1/8 shard); every rank takes the same decisions because they derive from all-reduced totals.
     bool strict = false, labelled = false, stop = false;
+    int tiles_next = LLOYD_TILES_FULL;   // how the device would run the next tile sweep: decides the form of the final E-step
     const bool trace = getenv("OFC_LLOYD_TRACE") != nullptr;
     int it = 0;
     const int *halt = &st->halt;
@@ -246,8 +248,9 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             // run in the mode k_lloyd_update chose from the previous iteration's tile counts (lloyd_tiles.hip)
             const int tiles = (prune && !labelled) ? (it + w == 0 ? 1 : 2) : 0;
             if (tiles)
-                OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.partial.as<double>(),
-                                           nblocks, tiles == 1, it + w == 0, s));
+                OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr,
+                                           sc.partial.as<double>(), nblocks, tiles == 1 ? LLOYD_WHAT_BUILD : LLOYD_WHAT_SWEEP,
+                                           it + w == 0, s));
             else
                 OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
                                             labelled ? 1 : 3, it + w == 0, s));
@@ -266,7 +269,9 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             if (trace)
                 fprintf(stderr, "[ofc lloyd] it %d tiles_mode %d tested %.0f pure %.0f shift %.3e empty %d\n", it + w,
                         S.tiles_mode, S.tiles_tested, S.tiles_pure, S.shift_tot, S.n_empty);
+ 
             if (S.tiles_mode != -1) {
+                tiles_next = S.tiles_next;
                 sc.prune_stats[0] += 1;                                   // sweeps that went tile by tile
                 if (S.tiles_mode == LLOYD_TILES_PRUNED) {
                     sc.prune_stats[1] += 1;                               // ... of them pruned
@@ -296,7 +301,12 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     }
     if (!stop) it = max_iter - 1;        // ran out of iterations: n_iter = max_iter
     // ---- final E-step (only when not strictly converged) and inertia: one sweep ----
-    if (!strict)
+    const bool final_tiles = !strict && prune && !labelled && tiles_next == LLOYD_TILES_PRUNED;
+    sc.prune_stats[5] = final_tiles ? 1 : 0;
+    if (final_tiles)                        // the fit's tile metadata is valid and most tiles pass: those are not read
+        OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, labels_dev,
+                                   sc.partial.as<double>(), nblocks, LLOYD_WHAT_FINAL, 0, s));
+    else if (!strict)
         OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 2, 0, s));
     else
         OFC_TRY(launch_lloyd_inertia(X, dtype, N, d, st, labels_dev, sc.partial.as<double>(), nblocks, s));
@@ -355,7 +365,7 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
                           int what, int iters, float *ms_per_launch)
 {
     OFC_REQUIRE(X_dev && centers && mean && ms_per_launch && iters >= 1 && N >= 64, "bad arguments");
-    OFC_REQUIRE(what >= 0 && what <= 3, "what = %d outside 0..3", what);
+    OFC_REQUIRE(what >= 0 && what <= 4, "what = %d outside 0..4", what);
     if (!lloyd_tiles_supported(OFC_F32, 2, k)) { set_error("k=%d outside 1..8", k); return OFC_EUNSUPPORTED; }
     OFC_TRY(ensure_device(device));
     LloydScratch &sc = scratch_for(device);
@@ -367,6 +377,7 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
     if (sc.tile_box.bytes < need) {
         OFC_TRY(sc.tile_box.alloc(need));
         OFC_TRY(sc.tile_sum.alloc(need));
+        OFC_TRY(sc.tile_sq.alloc(need / 2));
     }
     if (sc.labels.bytes < (size_t)N) OFC_TRY(sc.labels.alloc((size_t)N));
     LloydState *st = sc.state.as<LloydState>();
@@ -381,13 +392,14 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
     auto launch = [&]() -> int {
         switch (what) {
         case 0: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 3, 0, s);
-        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 0, 0, s);
-        case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 1, 1, s);
-        default: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 2, 0, s);
+        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_SWEEP, 0, s);
+        case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_BUILD, 1, s);
+        case 3: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 2, 0, s);
+        default: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, sc.labels.as<uint8_t>(), partial, nblocks, LLOYD_WHAT_FINAL, 0, s);
         }
     };
-    if (what == 1) {      // the pruned sweep needs the tile metadata and its mode flag
-        OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, partial, nblocks, 1, 1, s));
+    if (what == 1 || what == 4) {      // the pruned sweeps need the tile metadata and the mode flag
+        OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_BUILD, 1, s));
         const int mode = LLOYD_TILES_PRUNED;
         OFC_HIP(hipMemcpyAsync(&st->prune_mode, &mode, sizeof(int), hipMemcpyHostToDevice, s));
     }

@@ -41,7 +41,7 @@ struct LloydStatus {
     double sqsum[LLOYD_DMAX];     // sum (x-mean)^2 per column (first iteration only)
     double tiles_tested, tiles_pure;   // k_lloyd_tiles: tiles box-tested (or checked for uniform labels while the metadata
     int tiles_mode;                    // is built) / found inside one cell; mode the sweep ran in (-1: not a tile sweep)
-    int pad;
+    int tiles_next;                    // mode chosen for the next tile sweep (LLOYD_TILES_*)
 };
 
 int lloyd_kmax(int k);
@@ -58,14 +58,14 @@ int launch_lloyd_assign(const void *X, int dtype, int64_t N, int d, int k, const
 constexpr int LLOYD_REC_EXTRA = 1 + LLOYD_DMAX + 2;     // slots behind the sums and counts
 constexpr int LLOYD_NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + LLOYD_REC_EXTRA;
 inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + LLOYD_REC_EXTRA; }
-// (u,v) stream (f32, d = 2, k <= 8) in 64-sample tiles, see lloyd_tiles.hip.  build: iteration 0 -- every tile by sample,
-// writes box[N/64] (lo_u, lo_v, hi_u, hi_v) and tsum[N/64] (sum of the centred samples) and counts label-uniform tiles;
-// otherwise the sweep runs in st->prune_mode.  Record layout as launch_lloyd_assign's mode 3.
+// (u,v) stream (f32, d = 2, k <= 8) in 64-sample tiles, see lloyd_tiles.hip.  what = LLOYD_WHAT_BUILD: iteration 0 -- every
+// tile read, box[N/64] (lo_u, lo_v, hi_u, hi_v), tsum[N/64] (sum of the centred samples) and tsq[N/64] (scatter about the
+// tile's own mean) written; LLOYD_WHAT_SWEEP: a later iteration, in st->prune_mode; LLOYD_WHAT_FINAL: the final E-step
+// (labels written, partial[block] = inertia share).  Record layout of the first two as launch_lloyd_assign's mode 3.
+enum { LLOYD_WHAT_SWEEP = 0, LLOYD_WHAT_BUILD = 1, LLOYD_WHAT_FINAL = 2 };
 bool lloyd_tiles_supported(int dtype, int d, int k);
-int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum,
-                       double *partial, int nblocks, int build, int first, hipStream_t s);
-// labelled: tot's n_changed slot is meaningful (mode 1); first: iteration 0, which also fixes st->tol from the
-// column sums of (x-mean)^2 in tot, n_total samples and tol_rel
+int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum, void *tsq,
+                       uint8_t *labels, double *partial, int nblocks, int what, int first, hipStream_t s);
 // tiles: 0 = the sweep was not a k_lloyd_tiles one, 1 = it built the tile metadata, 2 = it ran in st->prune_mode
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
                         double n_total, double tol_rel, LloydStatus *status, hipStream_t s, int tiles = 0);

@@ -407,6 +407,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
         status->strict = 0;
         for (int j = 0; j < k; j++) status->counts[j] = w[j];
         status->tiles_mode = -1;
+        status->tiles_next = LLOYD_TILES_FULL;
         status->tiles_tested = status->tiles_pure = 0;
         __threadfence_system();
         status->valid = 1;
@@ -464,6 +465,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
     // sample) of a full one: it pays while about a third of the tiles pass the box test; a sweep that is switched off is
     // re-examined by a PROBE (box tests counted, nothing skipped) after 6, 12, 24, ... full sweeps.
     status->tiles_mode = -1;
+    status->tiles_next = LLOYD_TILES_FULL;
     status->tiles_tested = status->tiles_pure = 0;
     if (tiles) {
         const double tested = tot[kmax * d + kmax + 1 + LLOYD_DMAX], pure = tot[kmax * d + kmax + 2 + LLOYD_DMAX];
@@ -472,8 +474,8 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
         int next = ran;
         if (st->prune_policy == LLOYD_PRUNE_ALWAYS) {
             next = LLOYD_TILES_PRUNED;
-        } else if (ran == -2) {           // `pure` = tiles with uniform labels: an upper bound of what the box test passes
-            next = frac >= 0.5 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
+        } else if (ran == -2) {           // the building sweep applies the box test to the boxes it forms
+            next = frac >= 0.45 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
             st->prune_backoff = 6;
             st->prune_cooldown = st->prune_backoff;
         } else if (ran == LLOYD_TILES_PRUNED) {
@@ -490,6 +492,7 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
             if (--st->prune_cooldown <= 0) next = LLOYD_TILES_PROBE;
         }
         st->prune_mode = next;
+        status->tiles_next = next;
         status->tiles_mode = ran;
         status->tiles_tested = tested;
         status->tiles_pure = pure;

@@ -12,8 +12,9 @@
 // box, and the tile contributes tsum[t] and 64 to cluster j without being read.  No drift tracking, no runner-up
 // distances (round 2's Hamerly attempt lost on exactly those).  Tiles that fail the test are walked sample by sample
 // by the same wave, 16 lanes per tile, four points per lane -- the arithmetic of k_lloyd_assign's mode 3.
-// The final E-step (labels, inertia) stays a full sweep of k_lloyd_assign: labels are the argmin against the final
-// centres sample by sample.
+// The final E-step uses the same test: a tile inside one cell of the FINAL centres gets its 64 label bytes without being
+// read (the test proves that every sample's argmin is that cell), and its inertia share comes from the tile's scatter
+// about its own mean, kept beside the box:  tsq[t] = sum |x - mean(tile)|^2  (8 B).
 //
 // Deterministic: a wave owns a fixed set of tile groups, every lane adds into its private LDS column in a fixed order,
 // columns and work-groups are folded in a fixed order (as in lloyd_kernels.hip).  The sums differ from the unpruned
@@ -46,33 +47,35 @@ __device__ __forceinline__ float row_max(float v)
 {
     v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); return fmaxf(v, row_ror<1>(v));
 }
-__device__ __forceinline__ int row_min(int v)
-{
-    v = min(v, row_ror<8>(v)); v = min(v, row_ror<4>(v)); v = min(v, row_ror<2>(v)); return min(v, row_ror<1>(v));
-}
-__device__ __forceinline__ int row_max(int v)
-{
-    v = max(v, row_ror<8>(v)); v = max(v, row_ror<4>(v)); v = max(v, row_ror<2>(v)); return max(v, row_ror<1>(v));
-}
 __device__ __forceinline__ double row_sum(double v)
 {
     v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
 }
 
-// BUILD: iteration 0 (every tile by sample, metadata written, label-uniform tiles counted).
-template <int KMAX, bool BUILD>
+enum { TILES_SWEEP = 0, TILES_BUILD = 1, TILES_FINAL = 2 };
+
+// WHAT = TILES_BUILD: iteration 0.  Every tile is read; its box, centred sum and scatter about its own mean are written;
+//        a tile whose freshly formed box passes the test contributes its sum, the others are walked by sample.
+// WHAT = TILES_SWEEP: iterations 1..: runs in st->prune_mode (full / pruned / probe).
+// WHAT = TILES_FINAL: the final E-step (labels + inertia, _kmeans.py:736-744): a tile inside one cell gets 64 equal label
+//        bytes and adds  sum |x - c_j|^2 = scatter(tile) + 64 |mean(tile) - c_j|^2  (both terms >= 0: no cancellation) without
+//        being read; the others are walked by sample with sklearn's per-sample distance.  partial[block] = inertia share.
+template <int KMAX, int WHAT>
 __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X, int64_t N,
                                                      const LloydState *__restrict__ st, v4f *__restrict__ box,
-                                                     v2d *__restrict__ tsum, double *__restrict__ partial, int first)
+                                                     v2d *__restrict__ tsum, double *__restrict__ tsq,
+                                                     uint8_t *__restrict__ labels, double *__restrict__ partial, int first)
 {
     constexpr int D = 2, k = KMAX;
     constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;
-    if (st->halt) return;               // speculatively enqueued behind the iteration that converged (uniform)
-    const int mode = BUILD ? LLOYD_TILES_FULL : st->prune_mode;
+    constexpr bool BUILD = WHAT == TILES_BUILD, FINAL = WHAT == TILES_FINAL, ACCUM = !FINAL;
+    if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
+    const int mode = WHAT == TILES_SWEEP ? st->prune_mode : LLOYD_TILES_PRUNED;
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                             // [k*D][256]
     unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
     __shared__ unsigned s_tiles[4][2];
+    __shared__ double s_cen[KMAX][4];               // (c_x, c_y, |c|^2, -) per cluster
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
     double c[KMAX * D], cn[KMAX], m[D];
 #pragma unroll
@@ -83,9 +86,17 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
     }
 #pragma unroll
     for (int f = 0; f < D; f++) m[f] = st->mean[f];
-    for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
-    for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
-    double sq[D] = {0, 0};
+    if (ACCUM) {
+        for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
+        for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
+    }
+    if (tid < KMAX) {
+        s_cen[tid][0] = st->centers[tid * D];
+        s_cen[tid][1] = st->centers[tid * D + 1];
+        s_cen[tid][2] = st->cn[tid];
+    }
+    __syncthreads();
+    double sq[D] = {0, 0}, inert = 0;
     unsigned n_tested = 0, n_pure = 0;
 
     auto label_of = [&](const double (&x)[D]) {
@@ -98,49 +109,105 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         }
         return label;
     };
+    // c[j] for a lane-varying j: from LDS (a select chain over the register copies is turned into a dynamically indexed
+    // private array by the compiler, i.e. scratch memory)
+    auto centre_of = [&](int j, double &cjx, double &cjy, double &cnj) {
+        cjx = s_cen[j][0]; cjy = s_cen[j][1]; cnj = s_cen[j][2];
+    };
+    // is the (centred) box inside one Voronoi cell?  -> its label, or -1
+    auto box_label = [&](double lox, double loy, double hix, double hiy) {
+        const double corner[D] = {lox, loy};
+        const int j = label_of(corner);         // the candidate; the test below proves or rejects it for the whole box
+        double cjx, cjy, cnj;
+        centre_of(j, cjx, cjy, cnj);
+        const double ax = fmax(fabs(lox), fabs(hix)), ay = fmax(fabs(loy), fabs(hiy));
+        bool pure = true;
+#pragma unroll
+        for (int q = 0; q < KMAX; q++) {
+            const double gx = c[q * D] - cjx, gy = c[q * D + 1] - cjy;
+            // max over the box of D_j - D_q
+            const double wmax = (cnj - cn[q]) + 2.0 * (fmax(lox * gx, hix * gx) + fmax(loy * gy, hiy * gy));
+            // every term that enters a sample's D_j, D_q, times 1e-12: >> their f64 rounding (~1e-15 of the same)
+            const double mag = (fabs(cnj) + fabs(cn[q])) +
+                               4.0 * (ax * (fabs(c[q * D]) + fabs(cjx)) + ay * (fabs(c[q * D + 1]) + fabs(cjy)));
+            pure = pure && (q == j || wmax < -1e-12 * mag);
+        }
+        return pure ? j : -1;
+    };
     auto accumulate = [&](int l, double x0, double x1, unsigned n) {
         sacc[(l * D) * 256 + tid] += x0;
         sacc[(l * D + 1) * 256 + tid] += x1;
         scnt[l * 256 + tid] += n;
+    };
+    auto sq_dist = [&](const double (&x)[D], int l) {         // _euclidean_dense_dense for d = 2 (lloyd_kernels.hip)
+#pragma clang fp contract(off)
+        double cjx, cjy, cnj;
+        centre_of(l, cjx, cjy, cnj);
+        double r = 0;
+        r += (x[0] - cjx) * (x[0] - cjx);
+        r += (x[1] - cjy) * (x[1] - cjy);
+        return r;
     };
     // four consecutive samples of tile t (this lane's quad of its row's tile)
     auto walk = [&](int64_t t, const v4f a, const v4f b) {
         double x[4][D];
         x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
         x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
-        int nl[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             x[p][0] -= m[0];
             x[p][1] -= m[1];
-            nl[p] = label_of(x[p]);
         }
-#pragma unroll
-        for (int p = 0; p < 4; p++) accumulate(nl[p], x[p][0], x[p][1], 1u);
-        if (first) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                sq[0] += x[p][0] * x[p][0];
-                sq[1] += x[p][1] * x[p][1];
-            }
-        }
+        int tl = -1;                                    // BUILD: the tile's label if its box lies inside one cell
         if (BUILD) {
+            if (first) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    sq[0] += x[p][0] * x[p][0];
+                    sq[1] += x[p][1] * x[p][1];
+                }
+            }
             const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
             const float lv = row_min(fminf(fminf(a.y, a.w), fminf(b.y, b.w)));
             const float hu = row_max(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)));
             const float hv = row_max(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)));
             const double su = row_sum((x[0][0] + x[1][0]) + (x[2][0] + x[3][0]));
             const double sv = row_sum((x[0][1] + x[1][1]) + (x[2][1] + x[3][1]));
-            const int l0 = row_min(min(min(nl[0], nl[1]), min(nl[2], nl[3])));
-            const int l1 = row_max(max(max(nl[0], nl[1]), max(nl[2], nl[3])));
+            // scatter about the tile's own mean (exact division by 64): what the final E-step needs for a skipped tile
+            const double mu = su * 0.015625, mv = sv * 0.015625;
+            double ss = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const double du = x[p][0] - mu, dv = x[p][1] - mv;
+                ss += du * du + dv * dv;
+            }
+            ss = row_sum(ss);
+            const bool finite = (su == su && sv == sv);        // a NaN anywhere in the tile poisons its sums
+            if (finite) tl = box_label((double)lu - m[0], (double)lv - m[1], (double)hu - m[0], (double)hv - m[1]);
             if (r16 == 0) {
                 v4f bx = {lu, lv, hu, hv};
-                if (!(su == su && sv == sv)) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-                box[t] = bx;                        // a tile with a NaN in it never passes the box test
+                if (!finite) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                box[t] = bx;                            // a tile with a NaN in it never passes the box test
                 tsum[t] = v2d{su, sv};
+                tsq[t] = ss;
                 n_tested += 1u;
-                n_pure += (l0 == l1);
+                n_pure += (tl >= 0);
+                if (tl >= 0) accumulate(tl, su, sv, 64u);
             }
+            if (tl >= 0) return;                        // row-uniform
+        }
+        int nl[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) nl[p] = label_of(x[p]);
+        if (ACCUM) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) accumulate(nl[p], x[p][0], x[p][1], 1u);
+        }
+        if (FINAL) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) inert += sq_dist(x[p], nl[p]);
+            __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)),
+                                        reinterpret_cast<unsigned *>(labels) + t * 16 + r16);
         }
     };
 
@@ -151,40 +218,32 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         const int64_t t = g * 64 + lane;
         const bool valid = t < NT;
         unsigned long long todo;                    // tiles of this group that are walked by sample (wave-uniform)
-        if (mode == LLOYD_TILES_FULL) {
+        if (BUILD || mode == LLOYD_TILES_FULL) {
             todo = __ballot(valid);
         } else {
-            bool pure = false;
-            int j = 0;
+            int j = -1;
             if (valid) {
                 const v4f b = box[t];
-                const double lox = (double)b.x - m[0], loy = (double)b.y - m[1];
-                const double hix = (double)b.z - m[0], hiy = (double)b.w - m[1];
-                const double corner[D] = {lox, loy};
-                j = label_of(corner);               // the candidate; the test below proves or rejects it for the whole box
-                double cjx = c[0], cjy = c[1], cnj = cn[0];
-#pragma unroll
-                for (int q = 1; q < KMAX; q++)
-                    if (j == q) { cjx = c[q * D]; cjy = c[q * D + 1]; cnj = cn[q]; }
-                const double ax = fmax(fabs(lox), fabs(hix)), ay = fmax(fabs(loy), fabs(hiy));
-                pure = true;
-#pragma unroll
-                for (int q = 0; q < KMAX; q++) {
-                    const double gx = c[q * D] - cjx, gy = c[q * D + 1] - cjy;
-                    // max over the box of D_j - D_q
-                    const double wmax = (cnj - cn[q]) + 2.0 * (fmax(lox * gx, hix * gx) + fmax(loy * gy, hiy * gy));
-                    // every term that enters a sample's D_j, D_q, times 1e-12: >> their f64 rounding (~1e-15 of the same)
-                    const double mag = (fabs(cnj) + fabs(cn[q])) +
-                                       4.0 * (ax * (fabs(c[q * D]) + fabs(cjx)) + ay * (fabs(c[q * D + 1]) + fabs(cjy)));
-                    pure = pure && (q == j || wmax < -1e-12 * mag);
-                }
+                j = box_label((double)b.x - m[0], (double)b.y - m[1], (double)b.z - m[0], (double)b.w - m[1]);
                 n_tested += 1u;
-                n_pure += pure;
+                n_pure += (j >= 0);
             }
-            const bool skip = pure && mode == LLOYD_TILES_PRUNED;
+            const bool skip = j >= 0 && mode == LLOYD_TILES_PRUNED;
             if (skip) {
                 const v2d s = tsum[t];
-                accumulate(j, s.x, s.y, 64u);
+                if (ACCUM) accumulate(j, s.x, s.y, 64u);
+                if (FINAL) {
+#pragma clang fp contract(off)
+                    double cjx, cjy, cnj;
+                    centre_of(j, cjx, cjy, cnj);
+                    const double du = s.x * 0.015625 - cjx, dv = s.y * 0.015625 - cjy;
+                    inert += tsq[t] + 64.0 * (du * du + dv * dv);
+                    const unsigned w4 = (unsigned)j * 0x01010101u;
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    v4u *lp = reinterpret_cast<v4u *>(labels + t * 64);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) __builtin_nontemporal_store((v4u){w4, w4, w4, w4}, lp + q);
+                }
             }
             todo = __ballot(valid && !skip);
         }
@@ -222,11 +281,24 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
     if (blockIdx.x == 0 && tid < (int)(N - NT * 64)) {
         const int64_t i = NT * 64 + tid;
         double x[D] = {(double)X[i * 2] - m[0], (double)X[i * 2 + 1] - m[1]};
-        accumulate(label_of(x), x[0], x[1], 1u);
-        if (first) {
+        const int l = label_of(x);
+        if (ACCUM) accumulate(l, x[0], x[1], 1u);
+        if (BUILD && first) {
             sq[0] += x[0] * x[0];
             sq[1] += x[1] * x[1];
         }
+        if (FINAL) {
+            inert += sq_dist(x, l);
+            labels[i] = (uint8_t)l;
+        }
+    }
+    if (FINAL) {                                    // fixed order: shuffle tree, then waves 0..3
+        __shared__ double lds_in[4];
+        for (int off = 32; off >= 1; off >>= 1) inert += __shfl_down(inert, off, 64);
+        if (lane == 0) lds_in[wave] = inert;
+        __syncthreads();
+        if (tid == 0) partial[blockIdx.x] = ((lds_in[0] + lds_in[1]) + lds_in[2]) + lds_in[3];
+        return;
     }
     // ---- record: fold the 256 private columns in a fixed order (as k_lloyd_assign) ----
     double *rec = partial + (size_t)blockIdx.x * NV;
@@ -253,7 +325,7 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         rec[KMAX * D + KMAX + 1 + LLOYD_DMAX] = (double)(s_tiles[0][0] + s_tiles[1][0] + s_tiles[2][0] + s_tiles[3][0]);
         rec[KMAX * D + KMAX + 2 + LLOYD_DMAX] = (double)(s_tiles[0][1] + s_tiles[1][1] + s_tiles[2][1] + s_tiles[3][1]);
     }
-    if (first) {                                    // uniform: sum (x-mean)^2 per column for sklearn's tol
+    if (BUILD && first) {                           // uniform: sum (x-mean)^2 per column for sklearn's tol
         __shared__ double lds_sq[4 * D];
 #pragma unroll
         for (int f = 0; f < D; f++) {
@@ -269,28 +341,33 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
 bool lloyd_tiles_supported(int dtype, int d, int k) { return dtype == OFC_F32 && d == 2 && k >= 1 && k <= 8; }
 
 template <int KMAX>
-static void launch_tiles_k(const float *X, int64_t N, const LloydState *st, void *box, void *tsum, double *partial,
-                           int nblocks, int build, int first, hipStream_t s)
+static void launch_tiles_k(const float *X, int64_t N, const LloydState *st, void *box, void *tsum, void *tsq, uint8_t *labels,
+                           double *partial, int nblocks, int what, int first, hipStream_t s)
 {
     const size_t lds = (size_t)KMAX * (8 * 2 + 4) * 256;
-    if (build)
-        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, true>), dim3(nblocks), dim3(256), lds, s, X, N, st, (v4f *)box, (v2d *)tsum, partial, first);
+    v4f *b = (v4f *)box;
+    v2d *ts = (v2d *)tsum;
+    double *tq = (double *)tsq;
+    if (what == TILES_BUILD)
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_BUILD>), dim3(nblocks), dim3(256), lds, s, X, N, st, b, ts, tq, labels, partial, first);
+    else if (what == TILES_FINAL)
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_FINAL>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, labels, partial, 0);
     else
-        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, false>), dim3(nblocks), dim3(256), lds, s, X, N, st, (v4f *)box, (v2d *)tsum, partial, first);
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_SWEEP>), dim3(nblocks), dim3(256), lds, s, X, N, st, b, ts, tq, labels, partial, 0);
 }
 
-int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum,
-                       double *partial, int nblocks, int build, int first, hipStream_t s)
+int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum, void *tsq,
+                       uint8_t *labels, double *partial, int nblocks, int what, int first, hipStream_t s)
 {
     switch (k) {
-    case 1: launch_tiles_k<1>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 2: launch_tiles_k<2>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 3: launch_tiles_k<3>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 4: launch_tiles_k<4>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 5: launch_tiles_k<5>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 6: launch_tiles_k<6>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 7: launch_tiles_k<7>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
-    case 8: launch_tiles_k<8>(X, N, st, box, tsum, partial, nblocks, build, first, s); break;
+    case 1: launch_tiles_k<1>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 2: launch_tiles_k<2>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 3: launch_tiles_k<3>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 4: launch_tiles_k<4>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 5: launch_tiles_k<5>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 6: launch_tiles_k<6>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 7: launch_tiles_k<7>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 8: launch_tiles_k<8>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
     default: set_error("k=%d outside the tile sweep's range (1..8)", k); return OFC_EUNSUPPORTED;
     }
     OFC_HIP(hipGetLastError());

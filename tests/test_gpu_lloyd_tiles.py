@@ -81,8 +81,8 @@ def test_coherent_field_pruned_equals_oracle_and_unpruned(N):
     if N >= 64 * 64:
         assert st2["tile_sweeps"] == n_iter, st2          # every label-less iteration
         if n_iter > 1:
-            assert st2["pruned_sweeps"] >= 1 and st2["skip_fraction"] > 0.5, st2
-            assert st3["pruned_sweeps"] == st3["tile_sweeps"] - 1, st3
+            assert st2["pruned_sweeps"] >= 1 and st2["skip_fraction"] > 0.5 and st2["final_pruned"], st2
+            assert st3["pruned_sweeps"] == st3["tile_sweeps"] - 1 and st3["final_pruned"], st3
 
 
 def test_incoherent_field_switches_pruning_off_and_stays_exact():
@@ -97,7 +97,7 @@ def test_incoherent_field_switches_pruning_off_and_stays_exact():
     with prune(2):
         km, st = fit(X, C0)
     same_fit(km, cen, lab, inertia, n_iter)
-    assert st["pruned_sweeps"] == 0 and st["tile_sweeps"] >= 1, st
+    assert st["pruned_sweeps"] == 0 and st["tile_sweeps"] >= 1 and not st["final_pruned"], st
     with prune(3):
         km, st = fit(X, C0)
     same_fit(km, cen, lab, inertia, n_iter)
@@ -149,6 +149,28 @@ def test_loopback_world_with_tile_sweeps(world):
     assert km.n_iter_ == ref.n_iter_ and np.array_equal(km.labels_, ref.labels_[: len(X)])
     assert np.allclose(km.cluster_centers_, ref.cluster_centers_, rtol=1e-11, atol=1e-11)
     assert st["pruned_sweeps"] >= 1
+
+
+def test_tight_clusters_inertia_of_skipped_tiles():
+    """populations far apart, noise 1e-4: the inertia of a tile that is not read comes from its scatter about its own mean
+    plus 64 |mean - c|^2 (no cancellation), and must still meet the 1e-10 relative bar"""
+    X, vel = coherent_uv(64 * 2500 + 3, k=4, run=900, noise=1e-4, seed=21)
+    C0 = vel + 0.2
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, C0)
+    with prune(3):
+        km, st = fit(X, C0)
+    same_fit(km, cen, lab, inertia, n_iter)
+    assert st["final_pruned"] and st["skip_fraction"] > 0.8, st
+
+
+def test_sweep_bench_hook_runs_every_form():
+    from opticalflowclustering_amd import _lib, stages
+    X, vel = coherent_uv(64 * 3000, seed=2)
+    buf = _lib.DeviceBuffer(X.nbytes).upload(X)
+    mean = X.astype(np.float64).mean(0)
+    for what in range(5):
+        assert stages.bench_lloyd_sweep(buf.ptr, len(X), vel, mean, what, iters=2) > 0
+    buf.free()
 
 
 def test_prune_stats_rejects_null():

@@ -23,9 +23,10 @@ W, H = 1920, 1080
 want = {"k_polyexp": ("k_polyexp<1, false", 24 * W * H * 64, "64 x 1920x1080 images per launch"),
         "k_flow_iter": ("k_flow_iter<7, 0,", 56 * W * H * 32, "32 x 1920x1080 pairs per launch, level-0 iteration 2/3"),
         "k_lloyd_assign": ("k_lloyd_assign<2, 5, float, 3>", 8 * W * H * 299, "full label-less sweep, 299 x 1920x1080 (u,v) vectors"),
-        "k_lloyd_tiles_pruned": ("k_lloyd_tiles<5, false>", None, "pruned tile sweep over the same vectors, converged centres"),
-        "k_lloyd_tiles_build": ("k_lloyd_tiles<5, true>", 8 * W * H * 299 + 32 * W * H * 299 // 64, "metadata-building sweep (iteration 0)"),
-        "k_lloyd_final": ("k_lloyd_assign<2, 5, float, 2>", 9 * W * H * 299, "final E-step: labels written + inertia")}
+        "k_lloyd_tiles_pruned": ("k_lloyd_tiles<5, 0>", None, "pruned tile sweep over the same vectors, converged centres"),
+        "k_lloyd_tiles_build": ("k_lloyd_tiles<5, 1>", 8 * W * H * 299 + 40 * W * H * 299 // 64, "metadata-building sweep (iteration 0)"),
+        "k_lloyd_tiles_final": ("k_lloyd_tiles<5, 2>", None, "pruned final E-step: labels written + inertia"),
+        "k_lloyd_final": ("k_lloyd_assign<2, 5, float, 2>", 9 * W * H * 299, "full final E-step: labels written + inertia")}
 rec = {"source_sha16": bench.source_sha16(), "tag": tag, "kernels": {},
        "correction": "read bytes = 2 x FETCH_SIZE x 1024 (all read requests are 128 B: TCC_EA0_RDREQ_32B = 0 and "
                      "FETCH_SIZE x 1024 = TCC_EA0_RDREQ x 64); WRITE_SIZE x 1024 exact",
