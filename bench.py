@@ -259,7 +259,7 @@ def lloyd_roofline(pipe, centers, device):
     _lib.check(_lib.load().ofc_lloyd_colstats_dev(device, pipe.flows.ptr, _lib.F32, N, 2, None, 0, _lib.ptr(colsum)))
     mean = colsum / N
     ms = {name: stages.bench_lloyd_sweep(pipe.flows.ptr, N, centers, mean, what, 10, device)
-          for name, what in (("full", 0), ("pruned", 1), ("build", 2), ("final", 3), ("final_pruned", 4))}
+          for name, what in (("full", 0), ("pruned", 1), ("meta", 2), ("final", 3), ("final_pruned", 4))}
     alg = LLOYD_BYTES_PER_POINT * N
     return {"kernel": "k_lloyd_assign<2,5,float,3>", "bound": "hbm", "achieved": alg / (ms["full"] * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -267,10 +267,10 @@ def lloyd_roofline(pipe, centers, device):
             "algorithmic_bytes_per_launch": alg,
             "frac_at_10_bytes_per_point": 10 * N / (ms["full"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "the full label-less sweep (8 B/point; SURVEY.md 8d's 10 B/point form reads and writes a label byte as "
-                    "well).  The default fit runs it never: iteration 0 is `build_ms` (full read + 40 B of tile metadata "
-                    "written per 64 samples), iterations 1.. are `pruned_ms` each, the final E-step `final_estep_pruned_ms` "
-                    "(`final_estep_ms` = its full form, every sample read)",
-            "pruned_ms": ms["pruned"], "build_ms": ms["build"], "final_estep_ms": ms["final"],
+                    "well).  The default fit runs it never: one streaming pass builds the tile metadata (`meta_ms`: full read + "
+                    "40 B written per 64 samples), every iteration is a pruned sweep (`pruned_ms`), the final E-step "
+                    "`final_estep_pruned_ms` (`final_estep_ms` = its full form, every sample read)",
+            "pruned_ms": ms["pruned"], "meta_ms": ms["meta"], "final_estep_ms": ms["final"],
             "final_estep_pruned_ms": ms["final_pruned"],
             "pruned_traffic": pmc_traffic("k_lloyd_tiles_pruned")}
 

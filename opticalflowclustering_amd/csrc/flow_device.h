@@ -59,6 +59,21 @@ __device__ __forceinline__ void um_load(const float *__restrict__ R0, const floa
     }
 }
 
+// the fractions and the in-range flag again, from the same operands with the same operations as um_load: a caller that keeps
+// gathers in flight across other work need not hold these three registers per row meanwhile (the empty asm keeps the
+// compiler from recognising the common subexpression and carrying the first evaluation along)
+__device__ __forceinline__ void um_refrac(UmIn &u, int W, int H, int x, int y, float2 fl)
+{
+#pragma clang fp contract(off)
+    float flx = fl.x, fly = fl.y;
+    asm volatile("" : "+v"(flx), "+v"(fly));
+    float fx = (float)x + flx, fy = (float)y + fly;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    u.fx = fx - (float)x1;
+    u.fy = fy - (float)y1;
+    u.inr = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
+}
+
 __device__ __forceinline__ void um_math(const UmIn &u, int W, int H, int x, int y, float2 fl, float (&m)[5])
 {
 #pragma clang fp contract(off)

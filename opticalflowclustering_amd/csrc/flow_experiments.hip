@@ -1,7 +1,8 @@
 // flow_experiments.hip -- the round-2 experiments on the Farneback iteration, kept with their parity tests as the record of
 // what was measured ("Round 2"): k_flow_iter2 (two iterations per launch, OFC_FLOW_FUSE2) and
-// k_flow_iter_w3 (3 waves per SIMD, OFC_FLOW_W3).  Both are SLOWER than k_flow_iter on MI355X and never run unless their
-// switch is set; flow_kernels.hip holds what ships.
+// k_flow_iter_w3 (3 waves per SIMD, OFC_FLOW_W3); and round 3's k_flow_iter_p (gathers software-pipelined across steps, ring
+// partly in LDS, OFC_FLOW_PIPE).  All are SLOWER than k_flow_iter on MI355X and never run unless their switch is set;
+// flow_kernels.hip holds what ships.
 #include "flow_device.h"
 
 namespace ofc {
@@ -407,6 +408,256 @@ int launch_flow_iter2(const float *R, size_t frame_stride_R, const float *flow_i
     dim3 grid(cdiv(tx * ns, 8) * 8 * npair);
     hipLaunchKernelGGL((k_flow_iter2<MM, CC>), grid, dim3(2 * CC), 0, s, R, frame_stride_R, flow_in, flow_out, W, H,
                        rows_per_block, tx, ns, npair);
+    OFC_HIP(hipGetLastError());
+    return OFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_flow_iter, software-pipelined across steps (round 3; winsize 15, flow_in at this level's size).
+//
+// k_flow_iter's wave alternates between a memory phase (36 gathers of a 4-row step: issue, wait) and a compute phase
+// (matrix arithmetic, exchange, f64 horizontal sums, solve), and with the 80-VGPR ring only two waves fit a SIMD: a wave's
+// step lasts (memory + compute), and tools/gatherbench reproduces that additive law at this occupancy whatever the layout
+// of R.  Here the gathers of the NEXT step's rows 0,1 leave before this step's exchange and horizontal pass, rows 2,3
+// right after it, so that at most two rows of operands (56 VGPRs) are in flight while the horizontal pass needs its ~76
+// temporaries.  The registers for that come from the ring: 7 of its 16 slots live in LDS (35 KB, beside the 43.5 KB
+// exchange buffer: still two work-groups per CU).  Every slot index is a compile-time constant after unrolling.
+// Arithmetic, operand order and summation order are k_flow_iter's: the output is bit-identical (tested).
+//
+// RESULT (MI355X, 32 x 1080p pairs, level 0): 1.81-1.92 ms per iteration against k_flow_iter's 0.72-0.75.  The schedule does
+// not fit two waves per SIMD: with four rows of operands live across the step boundary (112 VGPRs), 45 ring registers, the
+// f64 window sums, three generations of flow vectors and the matrix arithmetic's temporaries the allocator spills 90-110
+// dwords per lane in every variant tried (two rows early / one row early / none early, channels of the horizontal pass
+// serialised, fractions recomputed instead of carried), and the scratch traffic of the spills exceeds the gather traffic
+// it was meant to hide.  Opt-in only (OFC_FLOW_PIPE=1); tools/flow_pipe_ab.py reproduces the comparison.
+// ------------------------------------------------------------------------------------------------
+constexpr int FP_NL = 7, FP_NR = 16 - FP_NL;      // ring slots FP_NR..15 in LDS, 0..FP_NR-1 in registers
+
+template <bool SUMS>
+__global__ __launch_bounds__(256, 2) void k_flow_iter_p(const float *__restrict__ Rb, size_t frame_stride_R,
+                                                        const float *__restrict__ flow_inb,
+                                                        float *__restrict__ flow_outb, int W, int H,
+                                                        int rows_per_block /* multiple of 16 */, int tiles_x,
+                                                        int n_strips, int npair, double *__restrict__ sums)
+{
+    constexpr int M = 7;
+    constexpr int TXO = 256 - 2 * M;
+    constexpr int NV = 2 * M + 4;
+    constexpr int NV2 = (NV + 1) / 2;
+    constexpr int PLD = 136, PITCH = 2 * PLD;
+    extern __shared__ __align__(16) unsigned char fp_smem[];
+    double (*vs)[BS_ROWS][PITCH] = reinterpret_cast<double (*)[BS_ROWS][PITCH]>(fp_smem);                       // [5][4][272]
+    float (*ringL)[5][256] = reinterpret_cast<float (*)[5][256]>(fp_smem + sizeof(double) * 5 * BS_ROWS * PITCH);   // [FP_NL][5][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = tiles_x * n_strips;
+    const int group = blockIdx.x / (8 * npair), rem = blockIdx.x - group * (8 * npair);
+    const int pair = rem >> 3, tile = group * 8 + (rem & 7);
+    if (tile >= tiles) {
+        if (SUMS && threadIdx.x < 2) sums[(size_t)blockIdx.x * 2 + threadIdx.x] = 0.0;     // padding work-group of the grid
+        return;
+    }
+    double su = 0, sv = 0;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * TXO;
+    const int y_begin = tile_y * rows_per_block;
+    const int y_end = min(y_begin + rows_per_block, H);
+    const size_t plane = (size_t)W * H;
+    const float *R0 = Rb + (size_t)pair * frame_stride_R;
+    const float *R1 = R0 + frame_stride_R;
+    const float2 *flow_in = reinterpret_cast<const float2 *>(flow_inb) + (size_t)pair * plane;
+    float2 *flow_out = reinterpret_cast<float2 *>(flow_outb) + (size_t)pair * plane;
+    const int xc = min(max(x0 - M + tid, 0), W - 1);
+    const int vs_w = ((tid >> 1) & 1) * PLD + 2 * (tid >> 2) + (tid & 1);
+    const double scale = 1.0 / ((2 * M + 1) * (2 * M + 1));
+
+    float ringR[FP_NR][5];
+    double v[5] = {0, 0, 0, 0, 0};
+    auto ring_put = [&](int slot, const float (&m)[5]) {         // slot: a constant after unrolling
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            if (slot < FP_NR) ringR[slot < FP_NR ? slot : 0][c] = m[c];
+            else ringL[slot >= FP_NR ? slot - FP_NR : 0][c][tid] = m[c];
+        }
+    };
+    auto ring_get = [&](int slot, int c) -> float {
+        return slot < FP_NR ? ringR[slot < FP_NR ? slot : 0][c] : ringL[slot >= FP_NR ? slot - FP_NR : 0][c][tid];
+    };
+    auto in_row = [&](int yc, int r) { return min(yc + r + 1 + M, H - 1); };     // row entering the window with output row yc + r
+
+    // ---- warm-up: rows y_begin-M .. y_begin+M (replicate-clamped), four at a time, as k_flow_iter ----
+#pragma unroll
+    for (int j4 = -M; j4 <= M; j4 += BS_ROWS) {
+        float2 flw[BS_ROWS];
+        UmIn uw[BS_ROWS];
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int q = 0; q < BS_ROWS; q++) flw[q] = flow_in[(size_t)min(max(y_begin + j4 + q, 0), H - 1) * W + xc];
+#pragma unroll
+        for (int q = 0; q < BS_ROWS; q++)
+            um_load(R0, R1, plane, W, H, xc, min(max(y_begin + j4 + q, 0), H - 1), flw[q], uw[q]);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int q = 0; q < BS_ROWS; q++) {
+            if (j4 + q <= M) {
+                const int row = min(max(y_begin + j4 + q, 0), H - 1);
+                float m[5];
+                um_math(uw[q], W, H, xc, row, flw[q], m);
+                ring_put((j4 + q + 16) & 15, m);
+#pragma unroll
+                for (int c = 0; c < 5; c++) v[c] += (double)m[c];
+            }
+        }
+    }
+
+    // ---- prologue of the pipeline: the first step's gathers in full, the flow vectors of the two steps behind it ----
+    float2 fl[BS_ROWS], fn[BS_ROWS], f2[BS_ROWS];
+    UmIn u[BS_ROWS];
+#pragma unroll
+    for (int r = 0; r < BS_ROWS; r++) fl[r] = flow_in[(size_t)in_row(y_begin, r) * W + xc];
+#pragma unroll
+    for (int r = 0; r < BS_ROWS; r++) fn[r] = flow_in[(size_t)in_row(y_begin + BS_ROWS, r) * W + xc];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int r = 0; r < BS_ROWS; r++) um_load(R0, R1, plane, W, H, xc, in_row(y_begin, r), fl[r], u[r]);
+    __builtin_amdgcn_s_setprio(0);
+
+    for (int y16 = y_begin; y16 < y_end; y16 += 16) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int yc = y16 + 4 * q4;
+            if (yc < y_end) {                                   // uniform
+                const bool more = yc + BS_ROWS < y_end;         // uniform: another step follows in this strip
+                // the barrier that frees `vs` from the previous step's readers comes first here (k_flow_iter has it behind
+                // the matrix arithmetic so that an early wave can start its gathers: here those are in flight already):
+                // every row's matrix entries then go straight into the window sums, the exchange buffer and the ring
+                __syncthreads();
+                __builtin_amdgcn_s_setprio(2);
+                auto consume = [&](int r) {                     // r: a constant after unrolling
+                    float mi[5];
+                    um_refrac(u[r], W, H, xc, in_row(yc, r), fl[r]);
+                    um_math(u[r], W, H, xc, in_row(yc, r), fl[r], mi);
+                    const int s_in = (4 * q4 + r + 1 + M) & 15, s_out = (4 * q4 + r + 16 - M) & 15;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        vs[c][r][vs_w] = v[c];
+                        v[c] += (double)mi[c] - (double)ring_get(s_out, c);
+                    }
+                    ring_put(s_in, mi);
+                };
+                // rows 0,1: requested before the previous step's exchange, long since here
+                consume(0);
+                consume(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {     // their registers take the next step's rows 0,1 at once; the flow vectors two steps ahead follow
+                    __builtin_amdgcn_s_setprio(3);
+                    um_load(R0, R1, plane, W, H, xc, in_row(yc + BS_ROWS, 0), fn[0], u[0]);
+                    um_load(R0, R1, plane, W, H, xc, in_row(yc + BS_ROWS, 1), fn[1], u[1]);
+#pragma unroll
+                    for (int r = 0; r < BS_ROWS; r++) f2[r] = flow_in[(size_t)in_row(yc + 2 * BS_ROWS, r) * W + xc];
+                    __builtin_amdgcn_s_setprio(2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // rows 2,3: requested after the previous step's horizontal pass
+                consume(2);
+                consume(3);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_s_setprio(0);
+                const int y = yc + wave;
+                const int xo = x0 + 4 * lane;
+                if (y < y_end && 4 * lane < TXO && xo < W) {
+                    double S[5][4];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double a[2 * NV2];
+#pragma unroll
+                        for (int q = 0; q < NV2; q++) {
+                            double2 d = *reinterpret_cast<const double2 *>(&vs[c][wave][(q & 1) * PLD + 2 * (lane + (q >> 1))]);
+                            a[2 * q] = d.x; a[2 * q + 1] = d.y;
+                        }
+                        double s = a[0];
+#pragma unroll
+                        for (int q = 1; q <= 2 * M; q++) s += a[q];
+                        S[c][0] = s;
+#pragma unroll
+                        for (int o = 1; o < 4; o++) {
+                            s += a[2 * M + o] - a[o - 1];
+                            S[c][o] = s;
+                        }
+                        // one channel's 18 window values at a time: two rows of the next step's operands are in flight in
+                        // registers meanwhile, and the scheduler would otherwise request all five channels' windows up front
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    float2 fo[4];
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        const double g11 = S[0][o] * scale, g12 = S[1][o] * scale, g22 = S[2][o] * scale,
+                                     h1 = S[3][o] * scale, h2 = S[4][o] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        fo[o] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                    }
+                    if (SUMS) {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+                            if (4 * lane + o < TXO && xo + o < W) { su += (double)fo[o].x; sv += (double)fo[o].y; }
+                    }
+                    float2 *dst = flow_out + (size_t)y * W + xo;
+                    if (4 * lane + 3 < TXO && xo + 3 < W && (W & 1) == 0) {      // 32 contiguous, 16-B aligned bytes
+                        reinterpret_cast<float4 *>(dst)[0] = make_float4(fo[0].x, fo[0].y, fo[1].x, fo[1].y);
+                        reinterpret_cast<float4 *>(dst)[1] = make_float4(fo[2].x, fo[2].y, fo[3].x, fo[3].y);
+                    } else {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+                            if (4 * lane + o < TXO && xo + o < W) dst[o] = fo[o];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {                                     // the next step's rows 2,3
+                    __builtin_amdgcn_s_setprio(3);
+                    um_load(R0, R1, plane, W, H, xc, in_row(yc + BS_ROWS, 2), fn[2], u[2]);
+                    um_load(R0, R1, plane, W, H, xc, in_row(yc + BS_ROWS, 3), fn[3], u[3]);
+                    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                    for (int r = 0; r < BS_ROWS; r++) { fl[r] = fn[r]; fn[r] = f2[r]; }
+                }
+            }
+        }
+    }
+    if (SUMS) {                 // fixed order: shuffle tree inside the wave, then waves 0..3 (as k_flow_iter)
+        for (int off = 32; off >= 1; off >>= 1) {
+            su += __shfl_down(su, off, 64);
+            sv += __shfl_down(sv, off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) { vs[0][0][2 * wave] = su; vs[0][0][2 * wave + 1] = sv; }
+        __syncthreads();
+        if (tid < 2) sums[(size_t)blockIdx.x * 2 + tid] = ((vs[0][0][tid] + vs[0][0][2 + tid]) + vs[0][0][4 + tid]) + vs[0][0][6 + tid];
+    }
+}
+
+constexpr size_t FP_LDS = sizeof(double) * 5 * BS_ROWS * 272 + sizeof(float) * FP_NL * 5 * 256;
+
+int launch_flow_iter_pipe(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                          int H, int rows_per_block, hipStream_t s, double *uv_sum, double *uv_scratch,
+                          size_t uv_scratch_doubles)
+{
+    static bool attr_set = false;       // 79,360 B of dynamic LDS: above the 64 KB default
+    if (!attr_set) {
+        OFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_iter_p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS));
+        OFC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_flow_iter_p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FP_LDS));
+        attr_set = true;
+    }
+    const int tx = cdiv(W, 256 - 14), ns = cdiv(H, rows_per_block);
+    const int grid = cdiv(tx * ns, 8) * 8 * npair;
+    if (uv_sum) {
+        if ((size_t)grid * 2 > uv_scratch_doubles) { set_error("flow sums: scratch too small (%d work-groups)", grid); return OFC_EINVAL; }
+        hipLaunchKernelGGL((k_flow_iter_p<true>), dim3(grid), dim3(256), FP_LDS, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                           rows_per_block, tx, ns, npair, uv_scratch);
+        OFC_HIP(hipGetLastError());
+        return launch_reduce_records(uv_scratch, grid, 2, uv_sum, s, nullptr);
+    }
+    hipLaunchKernelGGL((k_flow_iter_p<false>), dim3(grid), dim3(256), FP_LDS, s, R, frame_stride_R, flow_in, flow_out, W, H,
+                       rows_per_block, tx, ns, npair, nullptr);
     OFC_HIP(hipGetLastError());
     return OFC_OK;
 }

@@ -1219,6 +1219,14 @@ int launch_flow_iter(const float *R, size_t frame_stride_R, const float *flow_in
     UpsArgs u;
     u.src = coarse; u.sw = sw; u.sh = sh; u.mul = mul;
     u.scx = coarse ? (double)sw / W : 1.0; u.scy = coarse ? (double)sh / H : 1.0;
+    // OFC_FLOW_PIPE=1: the software-pipelined experiment of flow_experiments.hip (bit-identical output, 2.6x slower: it
+    // does not fit 256 VGPRs); read at every launch because its parity test toggles it
+    {
+        const char *e = getenv("OFC_FLOW_PIPE");
+        if (e && e[0] == '1' && winsize == 15 && !coarse)
+            return launch_flow_iter_pipe(R, frame_stride_R, flow_in, flow_out, npair, W, H, rows_per_block, s, uv_sum, uv_scratch,
+                                         uv_scratch_doubles);
+    }
     if (uv_sum) {               // the last iteration of level 0: also sum(u), sum(v) of the field it writes -> uv_sum[2]
         if (coarse || winsize != 15) { set_error("flow sums are emitted by the plain winsize-15 iteration only"); return OFC_EUNSUPPORTED; }
         const int tx = cdiv(W, 256 - 14), ns = cdiv(H, rows_per_block);

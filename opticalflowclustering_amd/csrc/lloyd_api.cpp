@@ -23,7 +23,8 @@ static size_t dtype_size(int dtype) { return dtype == OFC_U8 ? 1 : (dtype == OFC
 // pinned memory per call dominated small fits (rocprof hip-trace of a 38-frame shard).
 struct LloydScratch {
     DevBuf state, partial, tot, tot_local, excl, far, labels;
-    DevBuf tile_box, tile_sum, tile_sq;  // lloyd_tiles.hip: 16 + 16 + 8 B per 64-sample tile, rebuilt by every fit's iteration 0
+    DevBuf tile_box, tile_sum, tile_sq;  // lloyd_tiles.hip: 16 + 16 + 8 B per 64-sample tile, rebuilt by every fit (k_tile_meta)
+    DevBuf tile_meta;                    // k_tile_meta's reduced record (4 doubles)
     double prune_stats[6] = {0, 0, 0, 0, 0, 0};   // of the last fit, see ofc_lloyd_prune_stats
     LloydStatus *status = nullptr;       // pinned, device-visible; one slot per iteration of a window
     LloydStatus *status_dev = nullptr;
@@ -41,6 +42,7 @@ struct LloydScratch {
         OFC_TRY(tot_local.alloc(sizeof(double) * (NVMAX + 8)));
         OFC_TRY(excl.alloc(sizeof(int64_t) * LLOYD_KMAX));
         OFC_TRY(far.alloc(sizeof(double) * 2 * 2048));
+        OFC_TRY(tile_meta.alloc(sizeof(double) * 8));
         OFC_HIP(hipHostMalloc((void **)&status, sizeof(LloydStatus) * LLOYD_WINDOW, hipHostMallocMapped));
         OFC_HIP(hipHostGetDevicePointer((void **)&status_dev, status, 0));
         ready = true;
@@ -247,10 +249,15 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             // label-less sweeps of a (u,v) stream go tile by tile: iteration 0 builds the tile metadata, the later ones
             // run in the mode k_lloyd_update chose from the previous iteration's tile counts (lloyd_tiles.hip)
             const int tiles = (prune && !labelled) ? (it + w == 0 ? 1 : 2) : 0;
+            if (tiles == 1) {      // tile metadata + column sums of squares + sampled box test, then iteration 0 itself
+                OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr,
+                                           sc.partial.as<double>(), nblocks, LLOYD_WHAT_META, nullptr, s));
+                OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, 4, sc.tile_meta.as<double>(), s));
+            }
             if (tiles)
                 OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr,
-                                           sc.partial.as<double>(), nblocks, tiles == 1 ? LLOYD_WHAT_BUILD : LLOYD_WHAT_SWEEP,
-                                           it + w == 0, s));
+                                           sc.partial.as<double>(), nblocks, LLOYD_WHAT_SWEEP,
+                                           tiles == 1 ? sc.tile_meta.as<double>() : nullptr, s));
             else
                 OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks,
                                             labelled ? 1 : 3, it + w == 0, s));
@@ -305,7 +312,7 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
     sc.prune_stats[5] = final_tiles ? 1 : 0;
     if (final_tiles)                        // the fit's tile metadata is valid and most tiles pass: those are not read
         OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, labels_dev,
-                                   sc.partial.as<double>(), nblocks, LLOYD_WHAT_FINAL, 0, s));
+                                   sc.partial.as<double>(), nblocks, LLOYD_WHAT_FINAL, nullptr, s));
     else if (!strict)
         OFC_TRY(launch_lloyd_assign(X, dtype, N, d, k, st, labels_dev, sc.partial.as<double>(), nblocks, 2, 0, s));
     else
@@ -392,14 +399,14 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
     auto launch = [&]() -> int {
         switch (what) {
         case 0: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 3, 0, s);
-        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_SWEEP, 0, s);
-        case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_BUILD, 1, s);
+        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_SWEEP, nullptr, s);
+        case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_META, nullptr, s);
         case 3: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 2, 0, s);
-        default: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, sc.labels.as<uint8_t>(), partial, nblocks, LLOYD_WHAT_FINAL, 0, s);
+        default: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, sc.labels.as<uint8_t>(), partial, nblocks, LLOYD_WHAT_FINAL, nullptr, s);
         }
     };
     if (what == 1 || what == 4) {      // the pruned sweeps need the tile metadata and the mode flag
-        OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_BUILD, 1, s));
+        OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_META, nullptr, s));
         const int mode = LLOYD_TILES_PRUNED;
         OFC_HIP(hipMemcpyAsync(&st->prune_mode, &mode, sizeof(int), hipMemcpyHostToDevice, s));
     }

@@ -470,14 +470,11 @@ __global__ void k_lloyd_update(LloydState *st, const double *__restrict__ tot_g,
     if (tiles) {
         const double tested = tot[kmax * d + kmax + 1 + LLOYD_DMAX], pure = tot[kmax * d + kmax + 2 + LLOYD_DMAX];
         const double frac = tested > 0 ? pure / tested : 0.0;
-        const int ran = tiles == 1 ? -2 : st->prune_mode;       // -2: the sweep that built the metadata
+        // iteration 0 chose its own mode from k_tile_meta's sampled test: a full sweep tests no tile
+        const int ran = tiles == 1 ? (tested > 0 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL) : st->prune_mode;
         int next = ran;
         if (st->prune_policy == LLOYD_PRUNE_ALWAYS) {
             next = LLOYD_TILES_PRUNED;
-        } else if (ran == -2) {           // the building sweep applies the box test to the boxes it forms
-            next = frac >= 0.45 ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
-            st->prune_backoff = 6;
-            st->prune_cooldown = st->prune_backoff;
         } else if (ran == LLOYD_TILES_PRUNED) {
             if (frac < 0.3) {
                 next = LLOYD_TILES_FULL;

@@ -3,9 +3,11 @@
 // lloyd_api.cpp restates it; this file only changes HOW the label-less M-step record of an iteration is formed.
 //
 // The samples are cut into tiles of 64 consecutive ones (512 B; a row segment of the flow field, whose vectors are
-// close to each other inside a motion population).  Iteration 0 walks every sample and leaves per tile
+// close to each other inside a motion population).  Before iteration 0 one streaming pass (k_tile_meta) leaves per tile
 //     box[t]  = (min u, min v, max u, max v)      f32, 16 B
 //     tsum[t] = sum over the tile of (x - mean)   f64 x 2, 16 B      (the mean is fixed for the whole fit)
+//     tsq[t]  = sum |x - mean(tile)|^2            f64, 8 B           (for the final E-step's inertia)
+// and the column sums of (x - mean)^2 that sklearn's tol needs (_tolerance, _kmeans.py:279-287).
 // From then on a tile is tested before it is read: D_j(x) - D_j'(x) = (|c_j|^2 - |c_j'|^2) + 2 x.(c_j' - c_j) is linear
 // in x, so its maximum over the box sits at a corner; if it is negative (by a margin far above the rounding of the
 // sample-by-sample arithmetic) for every j' != j, every sample of the tile has label j whatever its position in the
@@ -52,160 +54,227 @@ __device__ __forceinline__ double row_sum(double v)
     v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); return v + row_ror<1>(v);
 }
 
-enum { TILES_SWEEP = 0, TILES_BUILD = 1, TILES_FINAL = 2 };
+// centres (centred, as sklearn iterates) in registers for the unrolled distance loop, and in LDS for a lane-varying index
+// (a select chain over the register copies is turned into a dynamically indexed private array, i.e. scratch memory)
+template <int KMAX> struct TileCtx {
+    double c[KMAX * 2], cn[KMAX], m[2];
+    const double (*s_cen)[4];                    // LDS: (c_x, c_y, |c|^2, -) per cluster
 
-// WHAT = TILES_BUILD: iteration 0.  Every tile is read; its box, centred sum and scatter about its own mean are written;
-//        a tile whose freshly formed box passes the test contributes its sum, the others are walked by sample.
-// WHAT = TILES_SWEEP: iterations 1..: runs in st->prune_mode (full / pruned / probe).
-// WHAT = TILES_FINAL: the final E-step (labels + inertia, _kmeans.py:736-744): a tile inside one cell gets 64 equal label
-//        bytes and adds  sum |x - c_j|^2 = scatter(tile) + 64 |mean(tile) - c_j|^2  (both terms >= 0: no cancellation) without
-//        being read; the others are walked by sample with sklearn's per-sample distance.  partial[block] = inertia share.
-template <int KMAX, int WHAT>
-__global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X, int64_t N,
-                                                     const LloydState *__restrict__ st, v4f *__restrict__ box,
-                                                     v2d *__restrict__ tsum, double *__restrict__ tsq,
-                                                     uint8_t *__restrict__ labels, double *__restrict__ partial, int first)
-{
-    constexpr int D = 2, k = KMAX;
-    constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;
-    constexpr bool BUILD = WHAT == TILES_BUILD, FINAL = WHAT == TILES_FINAL, ACCUM = !FINAL;
-    if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
-    const int mode = WHAT == TILES_SWEEP ? st->prune_mode : LLOYD_TILES_PRUNED;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *sacc = reinterpret_cast<double *>(smem);                             // [k*D][256]
-    unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
-    __shared__ unsigned s_tiles[4][2];
-    __shared__ double s_cen[KMAX][4];               // (c_x, c_y, |c|^2, -) per cluster
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
-    double c[KMAX * D], cn[KMAX], m[D];
+    __device__ __forceinline__ void load(const LloydState *st, double (*lds)[4])
+    {
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) {
-        cn[j] = st->cn[j];
-#pragma unroll
-        for (int f = 0; f < D; f++) c[j * D + f] = st->centers[j * D + f];
+        for (int j = 0; j < KMAX; j++) {
+            cn[j] = st->cn[j];
+            c[2 * j] = st->centers[2 * j];
+            c[2 * j + 1] = st->centers[2 * j + 1];
+        }
+        m[0] = st->mean[0];
+        m[1] = st->mean[1];
+        if (threadIdx.x < KMAX) {
+            lds[threadIdx.x][0] = st->centers[threadIdx.x * 2];
+            lds[threadIdx.x][1] = st->centers[threadIdx.x * 2 + 1];
+            lds[threadIdx.x][2] = st->cn[threadIdx.x];
+        }
+        s_cen = lds;
+        __syncthreads();
     }
-#pragma unroll
-    for (int f = 0; f < D; f++) m[f] = st->mean[f];
-    if (ACCUM) {
-        for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
-        for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
-    }
-    if (tid < KMAX) {
-        s_cen[tid][0] = st->centers[tid * D];
-        s_cen[tid][1] = st->centers[tid * D + 1];
-        s_cen[tid][2] = st->cn[tid];
-    }
-    __syncthreads();
-    double sq[D] = {0, 0}, inert = 0;
-    unsigned n_tested = 0, n_pure = 0;
-
-    auto label_of = [&](const double (&x)[D]) {
+    // first strict minimum of D_j = |c_j|^2 - 2 x.c_j (the arithmetic of lloyd_kernels.hip's assign_point for d = 2)
+    __device__ __forceinline__ int label_of(double x0, double x1) const
+    {
         double best = 0;
         int label = 0;
 #pragma unroll
         for (int j = 0; j < KMAX; j++) {
-            const double dj = cn[j] - 2.0 * fma(x[1], c[j * D + 1], x[0] * c[j * D]);
+            const double dj = cn[j] - 2.0 * fma(x1, c[2 * j + 1], x0 * c[2 * j]);
             if (j == 0 || dj < best) { best = dj; label = j; }
         }
         return label;
-    };
-    // c[j] for a lane-varying j: from LDS (a select chain over the register copies is turned into a dynamically indexed
-    // private array by the compiler, i.e. scratch memory)
-    auto centre_of = [&](int j, double &cjx, double &cjy, double &cnj) {
+    }
+    __device__ __forceinline__ void centre_of(int j, double &cjx, double &cjy, double &cnj) const
+    {
         cjx = s_cen[j][0]; cjy = s_cen[j][1]; cnj = s_cen[j][2];
-    };
+    }
     // is the (centred) box inside one Voronoi cell?  -> its label, or -1
-    auto box_label = [&](double lox, double loy, double hix, double hiy) {
-        const double corner[D] = {lox, loy};
-        const int j = label_of(corner);         // the candidate; the test below proves or rejects it for the whole box
+    __device__ __forceinline__ int box_label(double lox, double loy, double hix, double hiy) const
+    {
+        const int j = label_of(lox, loy);       // the candidate; the test below proves or rejects it for the whole box
         double cjx, cjy, cnj;
         centre_of(j, cjx, cjy, cnj);
         const double ax = fmax(fabs(lox), fabs(hix)), ay = fmax(fabs(loy), fabs(hiy));
         bool pure = true;
 #pragma unroll
         for (int q = 0; q < KMAX; q++) {
-            const double gx = c[q * D] - cjx, gy = c[q * D + 1] - cjy;
+            const double gx = c[2 * q] - cjx, gy = c[2 * q + 1] - cjy;
             // max over the box of D_j - D_q
             const double wmax = (cnj - cn[q]) + 2.0 * (fmax(lox * gx, hix * gx) + fmax(loy * gy, hiy * gy));
             // every term that enters a sample's D_j, D_q, times 1e-12: >> their f64 rounding (~1e-15 of the same)
             const double mag = (fabs(cnj) + fabs(cn[q])) +
-                               4.0 * (ax * (fabs(c[q * D]) + fabs(cjx)) + ay * (fabs(c[q * D + 1]) + fabs(cjy)));
+                               4.0 * (ax * (fabs(c[2 * q]) + fabs(cjx)) + ay * (fabs(c[2 * q + 1]) + fabs(cjy)));
             pure = pure && (q == j || wmax < -1e-12 * mag);
         }
         return pure ? j : -1;
-    };
-    auto accumulate = [&](int l, double x0, double x1, unsigned n) {
-        sacc[(l * D) * 256 + tid] += x0;
-        sacc[(l * D + 1) * 256 + tid] += x1;
-        scnt[l * 256 + tid] += n;
-    };
-    auto sq_dist = [&](const double (&x)[D], int l) {         // _euclidean_dense_dense for d = 2 (lloyd_kernels.hip)
+    }
+    // sklearn's per-sample squared distance for d = 2 (_euclidean_dense_dense, as lloyd_kernels.hip's sq_euclid_grouped)
+    __device__ __forceinline__ double sq_dist(double x0, double x1, int l) const
+    {
 #pragma clang fp contract(off)
         double cjx, cjy, cnj;
         centre_of(l, cjx, cjy, cnj);
         double r = 0;
-        r += (x[0] - cjx) * (x[0] - cjx);
-        r += (x[1] - cjy) * (x[1] - cjy);
+        r += (x0 - cjx) * (x0 - cjx);
+        r += (x1 - cjy) * (x1 - cjy);
         return r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// one streaming pass over the samples before iteration 0: tile metadata, column sums of (x - mean)^2, and the box test
+// against the INITIAL centres on every fourth step's tiles (a 1/4 sample: decides how iteration 0 runs).
+// 16 lanes <-> one tile, four samples per lane; a wave walks 4 tiles per step, the next step's samples requested first.
+// partial[block] = [sum (u-mean_u)^2, sum (v-mean_v)^2, tiles tested, tiles inside one cell]
+// ------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_tile_meta(const float *__restrict__ X, int64_t N,
+                                                   const LloydState *__restrict__ st, v4f *__restrict__ box,
+                                                   v2d *__restrict__ tsum, double *__restrict__ tsq,
+                                                   double *__restrict__ partial)
+{
+    __shared__ double s_cen[KMAX][4];
+    __shared__ double s_red[4][4];
+    TileCtx<KMAX> cx;
+    cx.load(st, s_cen);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
+    const int64_t NT = N >> 6;
+    const int64_t NS = (NT + 3) >> 2;               // steps of 4 tiles
+    const int64_t s0 = (int64_t)blockIdx.x * 4 + wave, ss = (int64_t)gridDim.x * 4;
+    double sq0 = 0, sq1 = 0;
+    unsigned n_tested = 0, n_pure = 0;
+    auto fetch = [&](int64_t s, v4f &a, v4f &b) {
+        const int64_t t = s * 4 + row;
+        if (s < NS && t < NT) {
+            const v4f *p = reinterpret_cast<const v4f *>(X + t * 128 + r16 * 8);
+            a = __builtin_nontemporal_load(p);
+            b = __builtin_nontemporal_load(p + 1);
+        }
+    };
+    v4f na = {0, 0, 0, 0}, nb = na;
+    fetch(s0, na, nb);
+    for (int64_t s = s0; s < NS; s += ss) {
+        const v4f a = na, b = nb;
+        fetch(s + ss, na, nb);
+        const int64_t t = s * 4 + row;
+        if (t < NT) {                               // row-uniform
+            const double x00 = (double)a.x - cx.m[0], x01 = (double)a.y - cx.m[1], x10 = (double)a.z - cx.m[0], x11 = (double)a.w - cx.m[1];
+            const double x20 = (double)b.x - cx.m[0], x21 = (double)b.y - cx.m[1], x30 = (double)b.z - cx.m[0], x31 = (double)b.w - cx.m[1];
+            sq0 += x00 * x00; sq0 += x10 * x10; sq0 += x20 * x20; sq0 += x30 * x30;
+            sq1 += x01 * x01; sq1 += x11 * x11; sq1 += x21 * x21; sq1 += x31 * x31;
+            const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
+            const float lv = row_min(fminf(fminf(a.y, a.w), fminf(b.y, b.w)));
+            const float hu = row_max(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)));
+            const float hv = row_max(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)));
+            const double su = row_sum((x00 + x10) + (x20 + x30));
+            const double sv = row_sum((x01 + x11) + (x21 + x31));
+            // scatter about the tile's own mean (exact division by 64): what the final E-step needs for a skipped tile
+            const double mu = su * 0.015625, mv = sv * 0.015625;
+            double sc = (x00 - mu) * (x00 - mu) + (x01 - mv) * (x01 - mv);
+            sc += (x10 - mu) * (x10 - mu) + (x11 - mv) * (x11 - mv);
+            sc += (x20 - mu) * (x20 - mu) + (x21 - mv) * (x21 - mv);
+            sc += (x30 - mu) * (x30 - mu) + (x31 - mv) * (x31 - mv);
+            sc = row_sum(sc);
+            const bool finite = (su == su && sv == sv);        // a NaN anywhere in the tile poisons its sums
+            int tl = -1;
+            const bool sampled = ((s / ss) & 3) == 0;           // wave-uniform: this wave's steps 0, 4, 8, ...
+            if (sampled && finite)
+                tl = cx.box_label((double)lu - cx.m[0], (double)lv - cx.m[1], (double)hu - cx.m[0], (double)hv - cx.m[1]);
+            if (r16 == 0) {
+                v4f bx = {lu, lv, hu, hv};
+                if (!finite) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                box[t] = bx;                        // a tile with a NaN in it never passes the box test
+                tsum[t] = v2d{su, sv};
+                tsq[t] = sc;
+                n_tested += sampled;
+                n_pure += (tl >= 0);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid < (int)(N - NT * 64)) {          // the samples behind the last full tile
+        const int64_t i = NT * 64 + tid;
+        const double x0 = (double)X[i * 2] - cx.m[0], x1 = (double)X[i * 2 + 1] - cx.m[1];
+        sq0 += x0 * x0;
+        sq1 += x1 * x1;
+    }
+    double v[4] = {sq0, sq1, (double)n_tested, (double)n_pure};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+        if (lane == 0) s_red[wave][i] = v[i];
+    }
+    __syncthreads();
+    if (tid < 4) partial[(size_t)blockIdx.x * 4 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+}
+
+enum { TILES_SWEEP = 0, TILES_FINAL = 1 };
+
+// WHAT = TILES_SWEEP: one label-less Lloyd iteration.  `meta` == nullptr: runs in st->prune_mode (full / pruned / probe).
+//        meta != nullptr (iteration 0): meta = k_tile_meta's reduced record; the sweep runs pruned if the sampled box test
+//        passed often enough (or the policy forces it), full otherwise, and carries meta's column sums of squares along.
+// WHAT = TILES_FINAL: the final E-step (labels + inertia, _kmeans.py:736-744): a tile inside one cell gets 64 equal label
+//        bytes and adds  sum |x - c_j|^2 = scatter(tile) + 64 |mean(tile) - c_j|^2  (both terms >= 0: no cancellation) without
+//        being read; the others are walked by sample with sklearn's per-sample distance.  partial[block] = inertia share.
+template <int KMAX, int WHAT>
+__global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X, int64_t N,
+                                                     const LloydState *__restrict__ st, const v4f *__restrict__ box,
+                                                     const v2d *__restrict__ tsum, const double *__restrict__ tsq,
+                                                     uint8_t *__restrict__ labels, double *__restrict__ partial,
+                                                     const double *__restrict__ meta)
+{
+    constexpr int D = 2, k = KMAX;
+    constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;
+    constexpr bool FINAL = WHAT == TILES_FINAL, ACCUM = !FINAL;
+    if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
+    int mode = LLOYD_TILES_PRUNED;
+    if (ACCUM) {
+        if (meta) mode = (st->prune_policy == LLOYD_PRUNE_ALWAYS || meta[3] >= 0.45 * meta[2]) ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
+        else mode = st->prune_mode;
+    }
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sacc = reinterpret_cast<double *>(smem);                             // [k*D][256]
+    unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
+    __shared__ unsigned s_tiles[4][2];
+    __shared__ double s_cen[KMAX][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
+    if (ACCUM) {
+        for (int i = 0; i < k * D; i++) sacc[i * 256 + tid] = 0.0;
+        for (int j = 0; j < k; j++) scnt[j * 256 + tid] = 0u;
+    }
+    TileCtx<KMAX> cx;
+    cx.load(st, s_cen);
+    double inert = 0;
+    unsigned n_tested = 0, n_pure = 0;
+    auto accumulate = [&](int l, double x0, double x1, unsigned n) {
+        sacc[(l * D) * 256 + tid] += x0;
+        sacc[(l * D + 1) * 256 + tid] += x1;
+        scnt[l * 256 + tid] += n;
     };
     // four consecutive samples of tile t (this lane's quad of its row's tile)
     auto walk = [&](int64_t t, const v4f a, const v4f b) {
         double x[4][D];
         x[0][0] = a.x; x[0][1] = a.y; x[1][0] = a.z; x[1][1] = a.w;
         x[2][0] = b.x; x[2][1] = b.y; x[3][0] = b.z; x[3][1] = b.w;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            x[p][0] -= m[0];
-            x[p][1] -= m[1];
-        }
-        int tl = -1;                                    // BUILD: the tile's label if its box lies inside one cell
-        if (BUILD) {
-            if (first) {
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    sq[0] += x[p][0] * x[p][0];
-                    sq[1] += x[p][1] * x[p][1];
-                }
-            }
-            const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
-            const float lv = row_min(fminf(fminf(a.y, a.w), fminf(b.y, b.w)));
-            const float hu = row_max(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)));
-            const float hv = row_max(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)));
-            const double su = row_sum((x[0][0] + x[1][0]) + (x[2][0] + x[3][0]));
-            const double sv = row_sum((x[0][1] + x[1][1]) + (x[2][1] + x[3][1]));
-            // scatter about the tile's own mean (exact division by 64): what the final E-step needs for a skipped tile
-            const double mu = su * 0.015625, mv = sv * 0.015625;
-            double ss = 0;
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const double du = x[p][0] - mu, dv = x[p][1] - mv;
-                ss += du * du + dv * dv;
-            }
-            ss = row_sum(ss);
-            const bool finite = (su == su && sv == sv);        // a NaN anywhere in the tile poisons its sums
-            if (finite) tl = box_label((double)lu - m[0], (double)lv - m[1], (double)hu - m[0], (double)hv - m[1]);
-            if (r16 == 0) {
-                v4f bx = {lu, lv, hu, hv};
-                if (!finite) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-                box[t] = bx;                            // a tile with a NaN in it never passes the box test
-                tsum[t] = v2d{su, sv};
-                tsq[t] = ss;
-                n_tested += 1u;
-                n_pure += (tl >= 0);
-                if (tl >= 0) accumulate(tl, su, sv, 64u);
-            }
-            if (tl >= 0) return;                        // row-uniform
-        }
         int nl[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) nl[p] = label_of(x[p]);
+        for (int p = 0; p < 4; p++) {
+            x[p][0] -= cx.m[0];
+            x[p][1] -= cx.m[1];
+            nl[p] = cx.label_of(x[p][0], x[p][1]);
+        }
         if (ACCUM) {
 #pragma unroll
             for (int p = 0; p < 4; p++) accumulate(nl[p], x[p][0], x[p][1], 1u);
         }
         if (FINAL) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) inert += sq_dist(x[p], nl[p]);
+            for (int p = 0; p < 4; p++) inert += cx.sq_dist(x[p][0], x[p][1], nl[p]);
             __builtin_nontemporal_store((unsigned)(nl[0] | (nl[1] << 8) | (nl[2] << 16) | (nl[3] << 24)),
                                         reinterpret_cast<unsigned *>(labels) + t * 16 + r16);
         }
@@ -218,13 +287,13 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         const int64_t t = g * 64 + lane;
         const bool valid = t < NT;
         unsigned long long todo;                    // tiles of this group that are walked by sample (wave-uniform)
-        if (BUILD || mode == LLOYD_TILES_FULL) {
+        if (mode == LLOYD_TILES_FULL) {
             todo = __ballot(valid);
         } else {
             int j = -1;
             if (valid) {
                 const v4f b = box[t];
-                j = box_label((double)b.x - m[0], (double)b.y - m[1], (double)b.z - m[0], (double)b.w - m[1]);
+                j = cx.box_label((double)b.x - cx.m[0], (double)b.y - cx.m[1], (double)b.z - cx.m[0], (double)b.w - cx.m[1]);
                 n_tested += 1u;
                 n_pure += (j >= 0);
             }
@@ -235,7 +304,7 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
                 if (FINAL) {
 #pragma clang fp contract(off)
                     double cjx, cjy, cnj;
-                    centre_of(j, cjx, cjy, cnj);
+                    cx.centre_of(j, cjx, cjy, cnj);
                     const double du = s.x * 0.015625 - cjx, dv = s.y * 0.015625 - cjy;
                     inert += tsq[t] + 64.0 * (du * du + dv * dv);
                     const unsigned w4 = (unsigned)j * 0x01010101u;
@@ -280,15 +349,11 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
     // the samples behind the last full tile
     if (blockIdx.x == 0 && tid < (int)(N - NT * 64)) {
         const int64_t i = NT * 64 + tid;
-        double x[D] = {(double)X[i * 2] - m[0], (double)X[i * 2 + 1] - m[1]};
-        const int l = label_of(x);
-        if (ACCUM) accumulate(l, x[0], x[1], 1u);
-        if (BUILD && first) {
-            sq[0] += x[0] * x[0];
-            sq[1] += x[1] * x[1];
-        }
+        const double x0 = (double)X[i * 2] - cx.m[0], x1 = (double)X[i * 2 + 1] - cx.m[1];
+        const int l = cx.label_of(x0, x1);
+        if (ACCUM) accumulate(l, x0, x1, 1u);
         if (FINAL) {
-            inert += sq_dist(x, l);
+            inert += cx.sq_dist(x0, x1, l);
             labels[i] = (uint8_t)l;
         }
     }
@@ -325,49 +390,40 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         rec[KMAX * D + KMAX + 1 + LLOYD_DMAX] = (double)(s_tiles[0][0] + s_tiles[1][0] + s_tiles[2][0] + s_tiles[3][0]);
         rec[KMAX * D + KMAX + 2 + LLOYD_DMAX] = (double)(s_tiles[0][1] + s_tiles[1][1] + s_tiles[2][1] + s_tiles[3][1]);
     }
-    if (BUILD && first) {                           // uniform: sum (x-mean)^2 per column for sklearn's tol
-        __shared__ double lds_sq[4 * D];
-#pragma unroll
-        for (int f = 0; f < D; f++) {
-            double a = sq[f];
-            for (int off = 32; off >= 1; off >>= 1) a += __shfl_down(a, off, 64);
-            if (lane == 0) lds_sq[wave * D + f] = a;
-        }
-        __syncthreads();
-        if (tid < D) rec[KMAX * D + KMAX + 1 + tid] = ((lds_sq[tid] + lds_sq[D + tid]) + lds_sq[2 * D + tid]) + lds_sq[3 * D + tid];
-    }
+    // iteration 0: sum (x-mean)^2 per column for sklearn's tol, formed by k_tile_meta, rides in work-group 0's record
+    if (meta && blockIdx.x == 0 && tid >= 64 && tid < 64 + D) rec[KMAX * D + KMAX + 1 + (tid - 64)] = meta[tid - 64];
 }
 
 bool lloyd_tiles_supported(int dtype, int d, int k) { return dtype == OFC_F32 && d == 2 && k >= 1 && k <= 8; }
 
 template <int KMAX>
 static void launch_tiles_k(const float *X, int64_t N, const LloydState *st, void *box, void *tsum, void *tsq, uint8_t *labels,
-                           double *partial, int nblocks, int what, int first, hipStream_t s)
+                           double *partial, int nblocks, int what, const double *meta, hipStream_t s)
 {
     const size_t lds = (size_t)KMAX * (8 * 2 + 4) * 256;
     v4f *b = (v4f *)box;
     v2d *ts = (v2d *)tsum;
     double *tq = (double *)tsq;
-    if (what == TILES_BUILD)
-        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_BUILD>), dim3(nblocks), dim3(256), lds, s, X, N, st, b, ts, tq, labels, partial, first);
-    else if (what == TILES_FINAL)
-        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_FINAL>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, labels, partial, 0);
+    if (what == LLOYD_WHAT_META)
+        hipLaunchKernelGGL((k_tile_meta<KMAX>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, partial);
+    else if (what == LLOYD_WHAT_FINAL)
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_FINAL>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, labels, partial, nullptr);
     else
-        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_SWEEP>), dim3(nblocks), dim3(256), lds, s, X, N, st, b, ts, tq, labels, partial, 0);
+        hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_SWEEP>), dim3(nblocks), dim3(256), lds, s, X, N, st, b, ts, tq, labels, partial, meta);
 }
 
 int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum, void *tsq,
-                       uint8_t *labels, double *partial, int nblocks, int what, int first, hipStream_t s)
+                       uint8_t *labels, double *partial, int nblocks, int what, const double *meta, hipStream_t s)
 {
     switch (k) {
-    case 1: launch_tiles_k<1>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 2: launch_tiles_k<2>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 3: launch_tiles_k<3>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 4: launch_tiles_k<4>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 5: launch_tiles_k<5>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 6: launch_tiles_k<6>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 7: launch_tiles_k<7>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
-    case 8: launch_tiles_k<8>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, first, s); break;
+    case 1: launch_tiles_k<1>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 2: launch_tiles_k<2>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 3: launch_tiles_k<3>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 4: launch_tiles_k<4>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 5: launch_tiles_k<5>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 6: launch_tiles_k<6>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 7: launch_tiles_k<7>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
+    case 8: launch_tiles_k<8>(X, N, st, box, tsum, tsq, labels, partial, nblocks, what, meta, s); break;
     default: set_error("k=%d outside the tile sweep's range (1..8)", k); return OFC_EUNSUPPORTED;
     }
     OFC_HIP(hipGetLastError());

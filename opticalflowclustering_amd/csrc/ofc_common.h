@@ -114,6 +114,10 @@ int launch_flow_iter2(const float *R, size_t frame_stride_R, const float *flow_i
 // one iteration, 3-waves-per-SIMD form (winsize 15, flow_in at this level's size)
 int launch_flow_iter_w3(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
                         int H, int winsize, hipStream_t s, int rows_per_block = 0);
+// round-3 experiment (flow_experiments.hip): k_flow_iter with the next step's gathers issued across the exchange (winsize 15)
+int launch_flow_iter_pipe(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
+                          int H, int rows_per_block, hipStream_t s, double *uv_sum, double *uv_scratch,
+                          size_t uv_scratch_doubles);
 int launch_flow_iter_stamped(const float *R, size_t frame_stride_R, const float *flow_in, float *flow_out, int npair, int W,
                              int H, hipStream_t s, unsigned long long *dbg, int *grid_out);
 int polyexp_default_rows(int W, int H, int nimg);

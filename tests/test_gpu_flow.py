@@ -400,3 +400,16 @@ def test_three_wave_iteration_kernel_equals_the_two_wave_one(st, W, H, rows):
     d = np.abs(one - w3)
     assert d.max() <= 1e-6 * max(1.0, np.abs(one).max()), d.max()
     assert (d == 0).mean() >= 0.999
+
+
+@pytest.mark.parametrize("W,H", [(480, 270), (700, 96), (243, 40), (1000, 300), (64, 16)])
+def test_pipelined_iteration_experiment_is_bit_identical(st, W, H, monkeypatch):
+    """k_flow_iter_p (round 3, OFC_FLOW_PIPE=1: the next step's gathers issued across the exchange, 7 ring slots in LDS):
+    same arithmetic, same operand and summation order as k_flow_iter -> the same bits.  (It is 2.6x slower -- it does not
+    fit 256 VGPRs -- and stays an opt-in record: csrc/flow_experiments.hip, tools/flow_pipe_ab.py.)"""
+    R0, R1, flow = _iter_case(W, H, seed=W + 7)
+    monkeypatch.setenv("OFC_FLOW_PIPE", "0")
+    plain = st.flow_iterate(R0, R1, flow, 3, mode=0)
+    monkeypatch.setenv("OFC_FLOW_PIPE", "1")
+    piped = st.flow_iterate(R0, R1, flow, 3, mode=0)
+    assert np.array_equal(plain, piped)

@@ -82,7 +82,7 @@ def test_coherent_field_pruned_equals_oracle_and_unpruned(N):
         assert st2["tile_sweeps"] == n_iter, st2          # every label-less iteration
         if n_iter > 1:
             assert st2["pruned_sweeps"] >= 1 and st2["skip_fraction"] > 0.5 and st2["final_pruned"], st2
-            assert st3["pruned_sweeps"] == st3["tile_sweeps"] - 1 and st3["final_pruned"], st3
+            assert st3["pruned_sweeps"] == st3["tile_sweeps"] and st3["final_pruned"], st3    # iteration 0 included
 
 
 def test_incoherent_field_switches_pruning_off_and_stays_exact():

@@ -18,6 +18,6 @@ centers, _, n_iter = pipe.run_kmeans(INIT)
 N = pipe.n_pairs * W * H
 colsum = np.zeros(2)
 _lib.check(_lib.load().ofc_lloyd_colstats_dev(0, pipe.flows.ptr, _lib.F32, N, 2, None, 0, _lib.ptr(colsum)))
-for name, what in (("full", 0), ("pruned", 1), ("build", 2), ("final", 3), ("final_pruned", 4)):
+for name, what in (("full", 0), ("pruned", 1), ("meta", 2), ("final", 3), ("final_pruned", 4)):
     print("lloyd", name, "ms", stages.bench_lloyd_sweep(pipe.flows.ptr, N, centers, colsum / N, what, n_ll))
 pipe.close()
