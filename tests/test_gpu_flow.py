@@ -413,3 +413,19 @@ def test_pipelined_iteration_experiment_is_bit_identical(st, W, H, monkeypatch):
     monkeypatch.setenv("OFC_FLOW_PIPE", "1")
     piped = st.flow_iterate(R0, R1, flow, 3, mode=0)
     assert np.array_equal(plain, piped)
+
+
+def test_graph_replay_of_a_batch_is_bit_identical(monkeypatch):
+    """OFC_FLOW_GRAPH=1: the launch sequence of a batch is captured into a HIP graph at its second occurrence and replayed
+    from the third on -- the same kernels with the same arguments, so the same field (and the same column sums)"""
+    from opticalflowclustering_amd.pipeline import ClipPipeline
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OFC_FLOW_GRAPH", mode)
+        pipe = ClipPipeline(480, 270, 6, batch_pairs=3, n_engines=2)
+        pipe.synth(t0=2, seed=0)
+        for _ in range(4):              # direct, capture, replay, replay
+            pipe.run_flow(stats=True)
+        out[mode] = (pipe.flows_host(), pipe.uv_sums.download((pipe.n_batches, 2), np.float64))
+        pipe.close()
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
