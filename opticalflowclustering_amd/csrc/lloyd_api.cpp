@@ -249,10 +249,12 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             // label-less sweeps of a (u,v) stream go tile by tile: iteration 0 builds the tile metadata, the later ones
             // run in the mode k_lloyd_update chose from the previous iteration's tile counts (lloyd_tiles.hip)
             const int tiles = (prune && !labelled) ? (it + w == 0 ? 1 : 2) : 0;
-            if (tiles == 1) {      // tile metadata + column sums of squares + sampled box test, then iteration 0 itself
+            if (tiles == 1) {      // is the field coherent enough? then tile metadata + column sums of squares, then iteration 0
+                OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, nullptr, nullptr, nullptr, nullptr,
+                                           sc.partial.as<double>(), nblocks, LLOYD_WHAT_PROBE, nullptr, s));
                 OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr,
                                            sc.partial.as<double>(), nblocks, LLOYD_WHAT_META, nullptr, s));
-                OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, 4, sc.tile_meta.as<double>(), s));
+                OFC_TRY(launch_reduce_records(sc.partial.as<double>(), nblocks, 2, sc.tile_meta.as<double>(), s));
             }
             if (tiles)
                 OFC_TRY(launch_lloyd_tiles((const float *)X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr,

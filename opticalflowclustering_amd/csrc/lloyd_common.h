@@ -59,17 +59,19 @@ constexpr int LLOYD_REC_EXTRA = 1 + LLOYD_DMAX + 2;     // slots behind the sums
 constexpr int LLOYD_NVMAX = LLOYD_KMAX * LLOYD_DMAX + LLOYD_KMAX + LLOYD_REC_EXTRA;
 inline int lloyd_record_len(int kmax, int d) { return kmax * d + kmax + LLOYD_REC_EXTRA; }
 // (u,v) stream (f32, d = 2, k <= 8) in 64-sample tiles, see lloyd_tiles.hip.
+//   LLOYD_WHAT_PROBE  before anything else: box test of a 1/64 sample of the tiles against the initial centres; sets
+//                     st->prune_mode, and st->prune_policy = OFF on the device when the field is too incoherent to pay
 //   LLOYD_WHAT_META   before iteration 0: box[N/64] (lo_u, lo_v, hi_u, hi_v), tsum[N/64] (sum of the centred samples),
-//                     tsq[N/64] (scatter about the tile's own mean) written; partial[block][4] = column sums of (x-mean)^2
-//                     and the sampled box test's (tiles tested, tiles inside one cell)
-//   LLOYD_WHAT_SWEEP  one label-less iteration; meta == nullptr: in st->prune_mode; else iteration 0 (meta = the reduced
-//                     META record, device pointer): pruned or full by the sampled test.  Record as launch_lloyd_assign's mode 3
+//                     tsq[N/64] (scatter about the tile's own mean) written; partial[block][2] = column sums of (x-mean)^2
+//                     (returns at once, records zeroed, when the probe switched the policy off)
+//   LLOYD_WHAT_SWEEP  one label-less iteration in st->prune_mode; meta != nullptr: iteration 0 (meta = the reduced META
+//                     record, device pointer: its sums of squares ride along).  Record as launch_lloyd_assign's mode 3
 //   LLOYD_WHAT_FINAL  the final E-step (labels written, partial[block] = inertia share)
-enum { LLOYD_WHAT_SWEEP = 0, LLOYD_WHAT_META = 1, LLOYD_WHAT_FINAL = 2 };
+enum { LLOYD_WHAT_SWEEP = 0, LLOYD_WHAT_META = 1, LLOYD_WHAT_FINAL = 2, LLOYD_WHAT_PROBE = 3 };
 bool lloyd_tiles_supported(int dtype, int d, int k);
 int launch_lloyd_tiles(const float *X, int64_t N, int k, const LloydState *st, void *box, void *tsum, void *tsq,
                        uint8_t *labels, double *partial, int nblocks, int what, const double *meta, hipStream_t s);
-// tiles: 0 = the sweep was not a k_lloyd_tiles one, 1 = iteration 0 (mode from the sampled test), 2 = it ran in st->prune_mode
+// tiles: 0 = the sweep was not a k_lloyd_tiles one, otherwise it ran in st->prune_mode (1: iteration 0)
 int launch_lloyd_update(LloydState *st, const double *tot, int k, int d, int after_reloc, int labelled, int first,
                         double n_total, double tol_rel, LloydStatus *status, hipStream_t s, int tiles = 0);
 constexpr int LLOYD_WINDOW = 16;    // most iterations enqueued per host synchronisation (windows grow 4, 8, 16, 16, ...)

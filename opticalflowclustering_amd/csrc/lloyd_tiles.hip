@@ -24,6 +24,8 @@
 // (tests/test_gpu_lloyd.py, bench.py's extras).
 #include "lloyd_common.h"
 
+#include <algorithm>
+
 namespace ofc {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -128,27 +130,87 @@ template <int KMAX> struct TileCtx {
 };
 
 // ------------------------------------------------------------------------------------------------
-// one streaming pass over the samples before iteration 0: tile metadata, column sums of (x - mean)^2, and the box test
-// against the INITIAL centres on every fourth step's tiles (a 1/4 sample: decides how iteration 0 runs).
-// 16 lanes <-> one tile, four samples per lane; a wave walks 4 tiles per step, the next step's samples requested first.
-// partial[block] = [sum (u-mean_u)^2, sum (v-mean_v)^2, tiles tested, tiles inside one cell]
+// Is the field coherent enough for the tile test to pay?  k_tile_probe forms the boxes of a 1/64 sample of the tiles and
+// tests them against the INITIAL centres (reads 1.6 % of the samples); k_tile_decide turns the policy off on the device
+// when fewer than 45 % pass: k_tile_meta then returns at once, every sweep runs full, and an incoherent field (white
+// noise over the populations) pays ~2 % of one sweep for having been asked instead of a whole metadata pass.
+// 16 lanes <-> one tile, four samples per lane, 4 tiles per wave step (as k_tile_meta).
 // ------------------------------------------------------------------------------------------------
 template <int KMAX>
+__global__ __launch_bounds__(256) void k_tile_probe(const float *__restrict__ X, int64_t N,
+                                                    const LloydState *__restrict__ st, double *__restrict__ partial)
+{
+    __shared__ double s_cen[KMAX][4];
+    __shared__ unsigned s_red[4][2];
+    TileCtx<KMAX> cx;
+    cx.load(st, s_cen);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
+    const int64_t NT = N >> 6, NS = (NT + 3) >> 2;
+    const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t stride = NS > 64 * nw ? 64 : (NS > nw ? NS / nw : 1);      // every 64th step of a large field
+    unsigned n_tested = 0, n_pure = 0;
+    for (int64_t s = w * stride; s < NS; s += nw * stride) {
+        const int64_t t = s * 4 + row;
+        if (t < NT) {                               // row-uniform
+            const v4f *p = reinterpret_cast<const v4f *>(X + t * 128 + r16 * 8);
+            const v4f a = p[0], b = p[1];
+            const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
+            const float lv = row_min(fminf(fminf(a.y, a.w), fminf(b.y, b.w)));
+            const float hu = row_max(fmaxf(fmaxf(a.x, a.z), fmaxf(b.x, b.z)));
+            const float hv = row_max(fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w)));
+            const int tl = cx.box_label((double)lu - cx.m[0], (double)lv - cx.m[1], (double)hu - cx.m[0], (double)hv - cx.m[1]);
+            if (r16 == 0) {
+                n_tested += 1u;
+                n_pure += (tl >= 0);
+            }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_tested += __shfl_down(n_tested, off, 64);
+        n_pure += __shfl_down(n_pure, off, 64);
+    }
+    if (lane == 0) { s_red[wave][0] = n_tested; s_red[wave][1] = n_pure; }
+    __syncthreads();
+    if (tid < 2) partial[(size_t)blockIdx.x * 2 + tid] = (double)(s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid]);
+}
+
+// one work-group: adds the probe's records and sets how the fit sweeps (st->prune_policy, st->prune_mode)
+__global__ void k_tile_decide(LloydState *st, const double *__restrict__ partial, int nblocks)
+{
+    __shared__ double s[2][64];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    s[0][threadIdx.x] = a;
+    s[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tested = 0, pure = 0;
+    for (int i = 0; i < 64; i++) { tested += s[0][i]; pure += s[1][i]; }
+    if (st->prune_policy != LLOYD_PRUNE_ALWAYS && !(pure >= 0.45 * tested && tested > 0)) st->prune_policy = LLOYD_PRUNE_OFF;
+    st->prune_mode = st->prune_policy == LLOYD_PRUNE_OFF ? LLOYD_TILES_FULL : LLOYD_TILES_PRUNED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one streaming pass over the samples before iteration 0: tile metadata and the column sums of (x - mean)^2.
+// 16 lanes <-> one tile, four samples per lane; a wave walks 4 tiles per step, the next step's samples requested first.
+// partial[block] = [sum (u-mean_u)^2, sum (v-mean_v)^2]; nothing is done when k_tile_decide switched the policy off.
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_meta(const float *__restrict__ X, int64_t N,
                                                    const LloydState *__restrict__ st, v4f *__restrict__ box,
                                                    v2d *__restrict__ tsum, double *__restrict__ tsq,
                                                    double *__restrict__ partial)
 {
-    __shared__ double s_cen[KMAX][4];
-    __shared__ double s_red[4][4];
-    TileCtx<KMAX> cx;
-    cx.load(st, s_cen);
+    __shared__ double s_red[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = lane >> 4, r16 = lane & 15;
+    if (st->prune_policy == LLOYD_PRUNE_OFF) {      // uniform
+        if (tid < 2) partial[(size_t)blockIdx.x * 2 + tid] = 0.0;
+        return;
+    }
+    const double m0 = st->mean[0], m1 = st->mean[1];
     const int64_t NT = N >> 6;
     const int64_t NS = (NT + 3) >> 2;               // steps of 4 tiles
     const int64_t s0 = (int64_t)blockIdx.x * 4 + wave, ss = (int64_t)gridDim.x * 4;
     double sq0 = 0, sq1 = 0;
-    unsigned n_tested = 0, n_pure = 0;
     auto fetch = [&](int64_t s, v4f &a, v4f &b) {
         const int64_t t = s * 4 + row;
         if (s < NS && t < NT) {
@@ -164,8 +226,8 @@ __global__ __launch_bounds__(256) void k_tile_meta(const float *__restrict__ X, 
         fetch(s + ss, na, nb);
         const int64_t t = s * 4 + row;
         if (t < NT) {                               // row-uniform
-            const double x00 = (double)a.x - cx.m[0], x01 = (double)a.y - cx.m[1], x10 = (double)a.z - cx.m[0], x11 = (double)a.w - cx.m[1];
-            const double x20 = (double)b.x - cx.m[0], x21 = (double)b.y - cx.m[1], x30 = (double)b.z - cx.m[0], x31 = (double)b.w - cx.m[1];
+            const double x00 = (double)a.x - m0, x01 = (double)a.y - m1, x10 = (double)a.z - m0, x11 = (double)a.w - m1;
+            const double x20 = (double)b.x - m0, x21 = (double)b.y - m1, x30 = (double)b.z - m0, x31 = (double)b.w - m1;
             sq0 += x00 * x00; sq0 += x10 * x10; sq0 += x20 * x20; sq0 += x30 * x30;
             sq1 += x01 * x01; sq1 += x11 * x11; sq1 += x21 * x21; sq1 += x31 * x31;
             const float lu = row_min(fminf(fminf(a.x, a.z), fminf(b.x, b.z)));
@@ -181,43 +243,36 @@ __global__ __launch_bounds__(256) void k_tile_meta(const float *__restrict__ X, 
             sc += (x20 - mu) * (x20 - mu) + (x21 - mv) * (x21 - mv);
             sc += (x30 - mu) * (x30 - mu) + (x31 - mv) * (x31 - mv);
             sc = row_sum(sc);
-            const bool finite = (su == su && sv == sv);        // a NaN anywhere in the tile poisons its sums
-            int tl = -1;
-            const bool sampled = ((s / ss) & 3) == 0;           // wave-uniform: this wave's steps 0, 4, 8, ...
-            if (sampled && finite)
-                tl = cx.box_label((double)lu - cx.m[0], (double)lv - cx.m[1], (double)hu - cx.m[0], (double)hv - cx.m[1]);
             if (r16 == 0) {
                 v4f bx = {lu, lv, hu, hv};
-                if (!finite) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-                box[t] = bx;                        // a tile with a NaN in it never passes the box test
+                // a NaN anywhere in the tile poisons its sums: such a tile never passes the box test
+                if (!(su == su && sv == sv)) bx = v4f{__builtin_inff(), __builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                box[t] = bx;
                 tsum[t] = v2d{su, sv};
                 tsq[t] = sc;
-                n_tested += sampled;
-                n_pure += (tl >= 0);
             }
         }
     }
     if (blockIdx.x == 0 && tid < (int)(N - NT * 64)) {          // the samples behind the last full tile
         const int64_t i = NT * 64 + tid;
-        const double x0 = (double)X[i * 2] - cx.m[0], x1 = (double)X[i * 2 + 1] - cx.m[1];
+        const double x0 = (double)X[i * 2] - m0, x1 = (double)X[i * 2 + 1] - m1;
         sq0 += x0 * x0;
         sq1 += x1 * x1;
     }
-    double v[4] = {sq0, sq1, (double)n_tested, (double)n_pure};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
-        if (lane == 0) s_red[wave][i] = v[i];
+    for (int off = 32; off >= 1; off >>= 1) {
+        sq0 += __shfl_down(sq0, off, 64);
+        sq1 += __shfl_down(sq1, off, 64);
     }
+    if (lane == 0) { s_red[wave][0] = sq0; s_red[wave][1] = sq1; }
     __syncthreads();
-    if (tid < 4) partial[(size_t)blockIdx.x * 4 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    if (tid < 2) partial[(size_t)blockIdx.x * 2 + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
 }
 
 enum { TILES_SWEEP = 0, TILES_FINAL = 1 };
 
-// WHAT = TILES_SWEEP: one label-less Lloyd iteration.  `meta` == nullptr: runs in st->prune_mode (full / pruned / probe).
-//        meta != nullptr (iteration 0): meta = k_tile_meta's reduced record; the sweep runs pruned if the sampled box test
-//        passed often enough (or the policy forces it), full otherwise, and carries meta's column sums of squares along.
+// WHAT = TILES_SWEEP: one label-less Lloyd iteration in st->prune_mode (full / pruned / probe).  meta != nullptr marks
+//        iteration 0, which owes the record the column sums of (x - mean)^2: k_tile_meta's reduced record `meta` when the
+//        metadata pass ran, formed here sample by sample when k_tile_decide switched the tile test off.
 // WHAT = TILES_FINAL: the final E-step (labels + inertia, _kmeans.py:736-744): a tile inside one cell gets 64 equal label
 //        bytes and adds  sum |x - c_j|^2 = scatter(tile) + 64 |mean(tile) - c_j|^2  (both terms >= 0: no cancellation) without
 //        being read; the others are walked by sample with sklearn's per-sample distance.  partial[block] = inertia share.
@@ -232,11 +287,9 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
     constexpr int NV = KMAX * D + KMAX + LLOYD_REC_EXTRA;
     constexpr bool FINAL = WHAT == TILES_FINAL, ACCUM = !FINAL;
     if (ACCUM && st->halt) return;      // speculatively enqueued behind the iteration that converged (uniform)
-    int mode = LLOYD_TILES_PRUNED;
-    if (ACCUM) {
-        if (meta) mode = (st->prune_policy == LLOYD_PRUNE_ALWAYS || meta[3] >= 0.45 * meta[2]) ? LLOYD_TILES_PRUNED : LLOYD_TILES_FULL;
-        else mode = st->prune_mode;
-    }
+    const int mode = ACCUM ? st->prune_mode : LLOYD_TILES_PRUNED;
+    const bool own_sq = ACCUM && meta && st->prune_policy == LLOYD_PRUNE_OFF;      // uniform
+    double sq0 = 0, sq1 = 0;
     extern __shared__ __align__(16) unsigned char smem[];
     double *sacc = reinterpret_cast<double *>(smem);                             // [k*D][256]
     unsigned *scnt = reinterpret_cast<unsigned *>(sacc + (size_t)k * D * 256);   // [k][256]
@@ -271,6 +324,13 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         if (ACCUM) {
 #pragma unroll
             for (int p = 0; p < 4; p++) accumulate(nl[p], x[p][0], x[p][1], 1u);
+            if (own_sq) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    sq0 += x[p][0] * x[p][0];
+                    sq1 += x[p][1] * x[p][1];
+                }
+            }
         }
         if (FINAL) {
 #pragma unroll
@@ -352,6 +412,10 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         const double x0 = (double)X[i * 2] - cx.m[0], x1 = (double)X[i * 2 + 1] - cx.m[1];
         const int l = cx.label_of(x0, x1);
         if (ACCUM) accumulate(l, x0, x1, 1u);
+        if (own_sq) {
+            sq0 += x0 * x0;
+            sq1 += x1 * x1;
+        }
         if (FINAL) {
             inert += cx.sq_dist(x0, x1, l);
             labels[i] = (uint8_t)l;
@@ -390,8 +454,20 @@ __global__ __launch_bounds__(256) void k_lloyd_tiles(const float *__restrict__ X
         rec[KMAX * D + KMAX + 1 + LLOYD_DMAX] = (double)(s_tiles[0][0] + s_tiles[1][0] + s_tiles[2][0] + s_tiles[3][0]);
         rec[KMAX * D + KMAX + 2 + LLOYD_DMAX] = (double)(s_tiles[0][1] + s_tiles[1][1] + s_tiles[2][1] + s_tiles[3][1]);
     }
-    // iteration 0: sum (x-mean)^2 per column for sklearn's tol, formed by k_tile_meta, rides in work-group 0's record
-    if (meta && blockIdx.x == 0 && tid >= 64 && tid < 64 + D) rec[KMAX * D + KMAX + 1 + (tid - 64)] = meta[tid - 64];
+    // iteration 0: sum (x-mean)^2 per column for sklearn's tol: formed by k_tile_meta (rides in work-group 0's record) or,
+    // with the tile test switched off, by this sweep
+    if (own_sq) {
+        __shared__ double lds_sq[4][2];
+        for (int off = 32; off >= 1; off >>= 1) {
+            sq0 += __shfl_down(sq0, off, 64);
+            sq1 += __shfl_down(sq1, off, 64);
+        }
+        if (lane == 0) { lds_sq[wave][0] = sq0; lds_sq[wave][1] = sq1; }
+        __syncthreads();
+        if (tid < D) rec[KMAX * D + KMAX + 1 + tid] = ((lds_sq[0][tid] + lds_sq[1][tid]) + lds_sq[2][tid]) + lds_sq[3][tid];
+    } else if (meta && blockIdx.x == 0 && tid >= 64 && tid < 64 + D) {
+        rec[KMAX * D + KMAX + 1 + (tid - 64)] = meta[tid - 64];
+    }
 }
 
 bool lloyd_tiles_supported(int dtype, int d, int k) { return dtype == OFC_F32 && d == 2 && k >= 1 && k <= 8; }
@@ -404,8 +480,12 @@ static void launch_tiles_k(const float *X, int64_t N, const LloydState *st, void
     v4f *b = (v4f *)box;
     v2d *ts = (v2d *)tsum;
     double *tq = (double *)tsq;
-    if (what == LLOYD_WHAT_META)
-        hipLaunchKernelGGL((k_tile_meta<KMAX>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, partial);
+    if (what == LLOYD_WHAT_PROBE) {
+        const int pb = std::min(nblocks, 256);
+        hipLaunchKernelGGL((k_tile_probe<KMAX>), dim3(pb), dim3(256), 0, s, X, N, st, partial);
+        hipLaunchKernelGGL(k_tile_decide, dim3(1), dim3(64), 0, s, const_cast<LloydState *>(st), partial, pb);
+    } else if (what == LLOYD_WHAT_META)
+        hipLaunchKernelGGL(k_tile_meta, dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, partial);
     else if (what == LLOYD_WHAT_FINAL)
         hipLaunchKernelGGL((k_lloyd_tiles<KMAX, TILES_FINAL>), dim3(nblocks), dim3(256), 0, s, X, N, st, b, ts, tq, labels, partial, nullptr);
     else

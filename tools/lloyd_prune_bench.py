@@ -40,3 +40,25 @@ os.environ["OFC_LLOYD_PRUNE"] = "1"
 os.environ["OFC_LLOYD_TRACE"] = "1"
 pipe.run_kmeans(INIT)
 pipe.close()
+
+# ---- the worst case for the tile test: the same five populations with NO spatial coherence (every sample drawn from a
+# random population), 2^26 samples: nothing can be skipped; what do the metadata pass and the policy cost? ----
+from opticalflowclustering_amd.cluster import kmeans_fit_dev
+del os.environ["OFC_LLOYD_TRACE"]
+rng = np.random.default_rng(0)
+N = 1 << 26
+vel = rng.uniform(-4, 4, (5, 2)).astype(np.float32)
+X = vel[rng.integers(0, 5, N)] + (0.3 * rng.standard_normal((N, 2))).astype(np.float32)
+buf = _lib.DeviceBuffer(X.nbytes).upload(X)
+lab = _lib.DeviceBuffer(N)
+C0 = vel.astype(np.float64) + 0.5
+for policy in ("0", "1", "0", "1"):
+    os.environ["OFC_LLOYD_PRUNE"] = policy
+    kmeans_fit_dev(buf.ptr, _lib.F32, N, 2, C0, labels_ptr=lab.ptr)
+    _lib.check(lib.ofc_device_sync(0))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        cen, inertia, n_iter = kmeans_fit_dev(buf.ptr, _lib.F32, N, 2, C0, labels_ptr=lab.ptr)
+    _lib.check(lib.ofc_device_sync(0))
+    print("incoherent field, OFC_LLOYD_PRUNE=%s: %.3f ms per fit, n_iter %d, %s" % (
+        policy, (time.perf_counter() - t0) / 5 * 1e3, n_iter, prune_stats()), flush=True)
