@@ -173,6 +173,58 @@ def test_sweep_bench_hook_runs_every_form():
     buf.free()
 
 
+def _tiles_two_rank_worker(rank, conn, split, q):
+    """one of two processes sharing the GPU: the in-library driver with tile sweeps on, its own (uneven) shard of a coherent
+    field, the per-iteration exchange over a pipe (ofc_dist_init_host)"""
+    import numpy as np
+    from opticalflowclustering_amd import _lib, dist
+    from opticalflowclustering_amd.cluster import kmeans_fit_dev, prune_stats
+    X, vel = coherent_uv(64 * 2200 + 29, seed=31)
+    cut = int(len(X) * split)
+    Xs = np.ascontiguousarray(X[:cut] if rank == 0 else X[cut:])
+    fn = {"sum": np.add, "max": np.maximum, "min": np.minimum}
+
+    def allreduce(arr, op):
+        conn.send(arr)
+        other = conn.recv()
+        return fn[op](arr, other) if rank == 0 else fn[op](other, arr)
+
+    dist.init_host(0, rank, 2, allreduce)
+    buf = _lib.DeviceBuffer(Xs.nbytes, 0).upload(Xs)
+    lab = _lib.DeviceBuffer(len(Xs), 0)
+    cen, inertia, n_iter = kmeans_fit_dev(buf.ptr, _lib.F32, len(Xs), 2, vel + 0.35, labels_ptr=lab.ptr)
+    labels = lab.download((len(Xs),), np.uint8)
+    st = prune_stats()
+    dist.finalize()
+    q.put((rank, cen, inertia, n_iter, labels.astype(np.int32), st))
+
+
+@pytest.mark.parametrize("split", [0.5, 0.23])
+def test_two_real_ranks_with_tile_sweeps(split, monkeypatch):
+    """two processes, different shards, every label-less iteration and the final E-step pruned on both: the all-reduced
+    records (incl. the tile counters) must give the single-process oracle fit"""
+    import multiprocessing as mp
+    monkeypatch.setenv("OFC_LLOYD_PRUNE", "2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    c0, c1 = ctx.Pipe()
+    procs = [ctx.Process(target=_tiles_two_rank_worker, args=(r, c, split, q)) for r, c in ((0, c0), (1, c1))]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    X, vel = coherent_uv(64 * 2200 + 29, seed=31)
+    cen, lab, inertia, n_iter = O.kmeans_fit(X, vel + 0.35)
+    assert res[0][3] == res[1][3] == n_iter
+    assert np.array_equal(np.concatenate([res[0][4], res[1][4]]), lab)
+    for r in res:
+        assert np.abs(r[1] - cen).max() <= 1e-9 and abs(r[2] - inertia) <= 1e-10 * inertia
+        assert r[5]["pruned_sweeps"] >= 1 and r[5]["final_pruned"], r[5]
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 def test_prune_stats_rejects_null():
     from opticalflowclustering_amd import _lib
     assert _lib.load().ofc_lloyd_prune_stats(0, None) == _lib.OFC_EINVAL
