@@ -204,7 +204,8 @@ int ofc_lloyd_prune_stats(int device, double *out6);
  * one sweep over the resident float32 (u,v) stream X_dev[N][2] with fixed centres (k x 2, uncentred) and column mean.
  * what = 0: the full label-less sweep (k_lloyd_assign mode 3, 8 B/sample); 1: the pruned tile sweep (metadata built first,
  * untimed); 2: the streaming pass that builds the tile metadata before iteration 0; 3: the full final E-step (labels + inertia, every sample
- * read); 4: the pruned final E-step (tiles inside one cell labelled without being read). */
+ * read); 4: the pruned final E-step (tiles inside one cell labelled without being read); 5: the tile sweep in its full mode
+ * (every tile walked by sample: what an incoherent field gets). */
 int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, const double *centers, const double *mean,
                           int what, int iters, float *ms_per_launch);
 /* ---- building blocks of a HOST-driven sharded fit (opticalflowclustering_amd/sharded.py): the same

@@ -374,7 +374,7 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
                           int what, int iters, float *ms_per_launch)
 {
     OFC_REQUIRE(X_dev && centers && mean && ms_per_launch && iters >= 1 && N >= 64, "bad arguments");
-    OFC_REQUIRE(what >= 0 && what <= 4, "what = %d outside 0..4", what);
+    OFC_REQUIRE(what >= 0 && what <= 5, "what = %d outside 0..5", what);
     if (!lloyd_tiles_supported(OFC_F32, 2, k)) { set_error("k=%d outside 1..8", k); return OFC_EUNSUPPORTED; }
     OFC_TRY(ensure_device(device));
     LloydScratch &sc = scratch_for(device);
@@ -401,15 +401,15 @@ int ofc_bench_lloyd_sweep(int device, const float *X_dev, int64_t N, int k, cons
     auto launch = [&]() -> int {
         switch (what) {
         case 0: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 3, 0, s);
-        case 1: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_SWEEP, nullptr, s);
+        case 1: case 5: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_SWEEP, nullptr, s);
         case 2: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_META, nullptr, s);
         case 3: return launch_lloyd_assign(X, OFC_F32, N, 2, k, st, sc.labels.as<uint8_t>(), partial, nblocks, 2, 0, s);
         default: return launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, sc.labels.as<uint8_t>(), partial, nblocks, LLOYD_WHAT_FINAL, nullptr, s);
         }
     };
-    if (what == 1 || what == 4) {      // the pruned sweeps need the tile metadata and the mode flag
+    if (what == 1 || what == 4 || what == 5) {      // the pruned sweeps need the tile metadata and the mode flag
         OFC_TRY(launch_lloyd_tiles(X, N, k, st, sc.tile_box.p, sc.tile_sum.p, sc.tile_sq.p, nullptr, partial, nblocks, LLOYD_WHAT_META, nullptr, s));
-        const int mode = LLOYD_TILES_PRUNED;
+        const int mode = what == 5 ? LLOYD_TILES_FULL : LLOYD_TILES_PRUNED;
         OFC_HIP(hipMemcpyAsync(&st->prune_mode, &mode, sizeof(int), hipMemcpyHostToDevice, s));
     }
     hipEvent_t e0, e1;

@@ -18,5 +18,5 @@ colsum = np.zeros(2)
 _lib.check(_lib.load().ofc_lloyd_colstats_dev(0, pipe.flows.ptr, _lib.F32, N, 2, None, 0, _lib.ptr(colsum)))
 for rep in range(2):
     print(" | ".join("%s %.3f" % (name, stages.bench_lloyd_sweep(pipe.flows.ptr, N, centers, colsum / N, what, 10))
-                     for name, what in (("full", 0), ("pruned", 1), ("meta", 2), ("final", 3), ("final_pruned", 4))))
+                     for name, what in (("full", 0), ("pruned", 1), ("meta", 2), ("final", 3), ("final_pruned", 4), ("tiles_full", 5))))
 pipe.close()
