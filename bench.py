@@ -48,8 +48,13 @@ MAX_BATCH = 32
 
 def auto_batch(n_pairs, max_batch=MAX_BATCH):
     """pairs per flow launch sequence.  A shard of a few batches is split evenly (38 pairs run 19 + 19 on the two
-    engines, never 32 + 6: measured 7.9 ms against 8.3 for one 38-pair batch); a long clip takes full 32-pair batches
-    and one short tail (299 pairs: 46.8 ms with 9 x 32 + 11 against 47.2 with 10 x 30)"""
+    engines, never 32 + 6: measured 7.9 ms against 8.3 for one 38-pair batch); a longer clip takes full 32-pair batches
+    and one short tail (299 pairs: 46.8 ms with 9 x 32 + 11 against 47.2 with 10 x 30); a clip of 256 pairs or more takes
+    64-pair batches (round 3: 36.5-36.9 against 37.5 ms per step -- at level 0 a 64-pair launch is exactly one work-group
+    per pair and column tile, 512 = one full round of the chip, each marching the whole frame height with a single 14-row
+    window warm-up; 48, 60, 75, 80, 100, 128, 150 pairs and a third engine were all slower)"""
+    if n_pairs >= 256:
+        return 2 * max_batch
     n_batches = -(-n_pairs // max_batch)
     return max_batch if n_batches >= 4 else -(-n_pairs // n_batches)
 

@@ -278,7 +278,6 @@ static int lloyd_fit_dev(int device, const void *X, int dtype, int64_t N, int d,
             if (trace)
                 fprintf(stderr, "[ofc lloyd] it %d tiles_mode %d tested %.0f pure %.0f shift %.3e empty %d\n", it + w,
                         S.tiles_mode, S.tiles_tested, S.tiles_pure, S.shift_tot, S.n_empty);
- 
             if (S.tiles_mode != -1) {
                 tiles_next = S.tiles_next;
                 sc.prune_stats[0] += 1;                                   // sweeps that went tile by tile
