@@ -104,6 +104,8 @@ def main():
     n_pairs_total = args.frames - 1
     p0, p1 = shard_pairs(n_pairs_total, world, rank)
     batch = args.batch if args.batch > 0 else auto_batch(p1 - p0)
+    if os.environ.get("OFC_BENCH_SCHEDULE"):          # experiment: an explicit schedule of batch sizes, e.g. "64,64,64,64,32,11"
+        batch = [int(v) for v in os.environ["OFC_BENCH_SCHEDULE"].split(",")]
     pipe = ClipPipeline(W, H, p1 - p0 + 1, batch_pairs=batch, device=device, n_engines=args.engines)
     pipe.synth(t0=p0, seed=0)
 
@@ -143,7 +145,7 @@ def main():
                                    "(0.5,3,15,3,5,1.2,0) + Lloyd k=5 over (u,v), frames sharded over %d GPU(s)"
                                    % (2 if world == 1 else 3, args.frames, world),
                        "width": W, "height": H, "frames": args.frames, "pairs": n_pairs_total, "k": K_CLUSTERS,
-                       "lloyd_iters": int(n_iter), "flow_batch_pairs": pipe.batch,
+                       "lloyd_iters": int(n_iter), "flow_batch_pairs": pipe.batch, "flow_batch_schedule": list(pipe.schedule),
                        "centers": [[float(v) for v in row] for row in centers], "inertia": float(inertia),
                        "parallelism": "frames sharded x%d, all-reduce of k*(d+1)+1 f64 per Lloyd iteration, transport %s"
                                       % (world, {"rccl": "RCCL", "gloo-host": "gloo (host fallback)", "none": "none (one rank)"}[dist.TRANSPORT])},

@@ -594,8 +594,10 @@ def test_flow_epilogue_column_sums_feed_the_fit(W, H, T, batch):
     pipe.run_flow(stats=True)
     flows = pipe.flows_host().astype(np.float64)
     sums = pipe.uv_sums.download((pipe.n_batches, 2), np.float64)
+    starts = np.concatenate([[0], np.cumsum(pipe.schedule)])
+    assert sorted(pipe.schedule, reverse=True)[0] == min(batch, T - 1) and sum(pipe.schedule) == T - 1
     for b in range(pipe.n_batches):
-        want = flows[b * batch:(b + 1) * batch].reshape(-1, 2).sum(0)
+        want = flows[starts[b]:starts[b + 1]].reshape(-1, 2).sum(0)
         assert np.abs(sums[b] - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (b, sums[b], want)
     init = np.array([[-3.0, -3.0], [-1.5, 1.0], [0.0, 0.0], [1.5, -1.0], [3.0, 3.0]])
     with_stats = pipe.run_kmeans(init)
