@@ -15,13 +15,15 @@
 // distances (round 2's Hamerly attempt lost on exactly those).  Tiles that fail the test are walked sample by sample
 // by the same wave, 16 lanes per tile, four points per lane -- the arithmetic of k_lloyd_assign's mode 3.
 // The final E-step uses the same test: a tile inside one cell of the FINAL centres gets its 64 label bytes without being
-// read (the test proves that every sample's argmin is that cell), and its inertia share comes from the tile's scatter
-// about its own mean, kept beside the box:  tsq[t] = sum |x - mean(tile)|^2  (8 B).
+// read (the test proves that every sample's argmin is that cell), and its inertia share is tsq[t] + 64 |mean(tile) - c_j|^2.
+// Whether any of this is used is decided on the device: k_tile_probe / k_tile_decide test a 1/64 sample of the tiles against
+// the initial centres first (an incoherent field skips the metadata pass and sweeps in full), and k_lloyd_update
+// (lloyd_kernels.hip) switches between pruned, full and counting-only sweeps from every iteration's all-reduced tile counts.
 //
 // Deterministic: a wave owns a fixed set of tile groups, every lane adds into its private LDS column in a fixed order,
 // columns and work-groups are folded in a fixed order (as in lloyd_kernels.hip).  The sums differ from the unpruned
 // sweep's in the last bits only (another summation order): centres agree to ~1e-15, labels and n_iter are the same
-// (tests/test_gpu_lloyd.py, bench.py's extras).
+// (tests/test_gpu_lloyd_tiles.py, bench.py's config.pruned_fit_check).
 #include "lloyd_common.h"
 
 #include <algorithm>
