@@ -106,6 +106,73 @@ __global__ __launch_bounds__(256) void k_gather(const float *__restrict__ R, con
     if (acc == 12345.678f) out[0] = acc;
 }
 
+
+// Ping-pong form: ONE 512-thread work-group per CU, its two halves (two 256-column tiles) in enforced anti-phase: while
+// one half runs a step's arithmetic (between the same two barriers a step of k_flow_iter has), the other half issues the
+// gathers of its next step and waits for them.  Every wave executes the same number of s_barrier per phase.  Same
+// registers per thread as the 256-thread form, same LDS per CU -- only the phases of the two tiles are tied together.
+__global__ __launch_bounds__(512) void k_pingpong(const float *__restrict__ R, float *out, int rows, int work)
+{
+    extern __shared__ float dyn_lds[];
+    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int x = min((blockIdx.x * 2 + half) * 242 + t, W - 1);
+    const int y0 = blockIdx.y * rows;
+    const size_t plane = (size_t)W * H;
+    const float *R0 = R + (size_t)blockIdx.z * plane * 5;
+    const float *R1 = R0 + plane * 5;
+    float acc = 0;
+    float v[4][25];
+    auto load = [&](int yb) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int y = min(yb + r, H - 1);
+            int x1, y1;
+            disp(x, y, x1, y1);
+            const unsigned i0 = (unsigned)y * W + x, i1 = (unsigned)y1 * W + x1;
+            const float *q = R0 + i0 * 5u;
+            const f4u a = *reinterpret_cast<const f4u *>(q);
+            v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w; v[r][4] = q[4];
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                const float *p = R1 + (i1 + (unsigned)tt * W) * 5u;
+                const f4u b = *reinterpret_cast<const f4u *>(p), c = *reinterpret_cast<const f4u *>(p + 4);
+                const f2u d = *reinterpret_cast<const f2u *>(p + 8);
+                float *o = &v[r][5 + 10 * tt];
+                o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = c.x; o[5] = c.y; o[6] = c.z; o[7] = c.w; o[8] = d.x; o[9] = d.y;
+            }
+        }
+    };
+    const int y_end = min(y0 + rows, H);
+    const int nsteps = (y_end - y0 + 3) / 4;
+    if (half == 0) load(y0);
+    __syncthreads();
+    for (int ph = 0; ph <= 2 * nsteps; ph++) {
+        const int step = (ph - half) >> 1;                  // the step this half computes (even phases: half 0)
+        if (((ph & 1) == half) && step >= 0 && step < nsteps) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 25; i++) acc += v[r][i];
+            __builtin_amdgcn_s_barrier();
+            float a0 = acc, a1 = acc + 1.f, a2 = acc + 2.f, a3 = acc + 3.f;
+            for (int i = 0; i < work; i++) {
+                a0 = fmaf(a0, 1.0001f, 0.5f); a1 = fmaf(a1, 1.0001f, 0.5f);
+                a2 = fmaf(a2, 1.0001f, 0.5f); a3 = fmaf(a3, 1.0001f, 0.5f);
+            }
+            acc = (a0 + a1) + (a2 + a3);
+            if (acc == 777.f) dyn_lds[threadIdx.x] = acc;
+            __builtin_amdgcn_s_barrier();
+        } else {
+            const int nstep = (ph + 1 - half) >> 1;          // the step this half computes in the NEXT phase
+            if (nstep >= 0 && nstep < nsteps && ((ph + 1) & 1) == half) load(y0 + 4 * nstep);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 template <class F> float timeit(F f, int iters)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -142,6 +209,13 @@ int main(int argc, char **argv)
     printf("A interleaved [px][5], unaligned x4   %.3f ms  (%.0f GB/s of 40 B/px unique)\n", ms, 40.0 * plane * NP / ms / 1e6);
     ms = timeit([&] { hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), lds, 0, R, RB, out, rows, work, stagger, sh); }, 10);
     printf("B split float4 + float, aligned x4    %.3f ms  (%.0f GB/s of 40 B/px unique)\n", ms, 40.0 * plane * NP / ms / 1e6);
+    if (work) {
+        const int lds2 = 90000;             // one 512-thread work-group per CU
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pingpong), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+        dim3 grid2(((W + 241) / 242 + 1) / 2, (H + rows - 1) / rows, NP);
+        ms = timeit([&] { hipLaunchKernelGGL(k_pingpong, grid2, dim3(512), lds2, 0, R, out, rows, work); }, 10);
+        printf("P ping-pong halves (interleaved R), 1 WG/CU  %.3f ms  (%.0f GB/s of 40 B/px unique)\n", ms, 40.0 * plane * NP / ms / 1e6);
+    }
     ms = timeit([&] { hipLaunchKernelGGL(k_gather<2>, grid, dim3(256), lds, 0, R, RB, out, rows, work, stagger, sh); }, 10);
     printf("C padded [px][8], aligned x4          %.3f ms  (%.0f GB/s of 64 B/px unique)\n", ms, 64.0 * plane * NP / ms / 1e6);
     return 0;
