@@ -20,20 +20,25 @@ def shard_pairs(n_pairs, world, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def batch_schedule(n_pairs, batch_pairs):
+    """sizes of the flow launch sequences a clip of n_pairs is cut into.  batch_pairs: pairs per batch, or an explicit schedule.
+    The short batch goes FIRST: at the end of a step both engines then finish on full batches instead of one of them running
+    a half-empty launch sequence alone (36.7 against 37.0 ms per 299-pair step)"""
+    if isinstance(batch_pairs, (list, tuple)):
+        schedule = [int(b) for b in batch_pairs]
+        if sum(schedule) != n_pairs or min(schedule) < 1:
+            raise ValueError(f"batch schedule {schedule} does not cover {n_pairs} pairs")
+        return schedule
+    b = max(1, min(int(batch_pairs), n_pairs))
+    return ([n_pairs % b] if n_pairs % b else []) + [b] * (n_pairs // b)
+
+
 class ClipPipeline:
     def __init__(self, W, H, n_frames_local, batch_pairs=16, params=None, device=0, n_engines=2):
         self.W, self.H, self.device = W, H, device
         self.n_frames = int(n_frames_local)
         self.n_pairs = self.n_frames - 1
-        # batch_pairs: pairs per flow launch sequence, or an explicit schedule of batch sizes (summing to n_pairs)
-        if isinstance(batch_pairs, (list, tuple)):
-            self.schedule = [int(b) for b in batch_pairs]
-            assert sum(self.schedule) == self.n_pairs and min(self.schedule) >= 1, (self.schedule, self.n_pairs)
-        else:
-            b = max(1, min(int(batch_pairs), self.n_pairs))
-            # the short batch goes FIRST: at the end of a step both engines then finish on full batches instead of one of them
-            # running a half-empty launch sequence alone (36.7 against 37.0 ms per 299-pair step)
-            self.schedule = ([self.n_pairs % b] if self.n_pairs % b else []) + [b] * (self.n_pairs // b)
+        self.schedule = batch_schedule(self.n_pairs, batch_pairs)
         self.batch = max(self.schedule)
         # two engines = two HIP streams: consecutive batches are independent, so their kernels overlap and fill
         # each other's tails / latency-bound phases

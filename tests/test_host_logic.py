@@ -180,3 +180,19 @@ def test_draw_grids_overlay_formats(tmp_path, monkeypatch):
     ys, xs = np.nonzero(canvas[..., 0])
     assert xs.min() >= 3 and xs.max() < 3 + tw and ys.max() <= 15 and ys.min() >= 15 - th + 1
     assert set("0123456789(), ") <= set(D._FONT)
+
+
+def test_batch_schedule_and_auto_batch():
+    """how a clip is cut into flow launch sequences (pipeline.batch_schedule, bench.auto_batch): covers every pair once,
+    short batch first, 64-pair batches for the 300-frame clip, an even split for a 1/8 shard"""
+    import bench
+    from opticalflowclustering_amd.pipeline import batch_schedule
+    assert batch_schedule(299, 64) == [43, 64, 64, 64, 64]
+    assert batch_schedule(38, 19) == [19, 19] and batch_schedule(5, 32) == [5] and batch_schedule(64, 64) == [64]
+    assert batch_schedule(10, [3, 7]) == [3, 7]
+    with pytest.raises(ValueError):
+        batch_schedule(10, [3, 6])
+    assert bench.auto_batch(299) == 64 and bench.auto_batch(38) == 19 and bench.auto_batch(150) == 32 and bench.auto_batch(75) == 25
+    for n in (1, 2, 37, 38, 75, 149, 150, 255, 256, 299, 999):
+        sch = batch_schedule(n, bench.auto_batch(n))
+        assert sum(sch) == n and max(sch) <= 64 and min(sch) >= 1
